@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the reference's own data files.
+
+Run ONCE in the build container (where /root/reference is mounted):
+
+    python tests/golden/make_golden.py
+
+It never imports reference code (the three scripts hard-import streamlit/librosa, which are absent);
+it only READS the reference's data artefacts, which are the de-facto known-answer tests of the path
+(SURVEY.md section 4):
+
+  clear_audio/<stem>.wav  ->  cache_features/<stem>_clean_feats.npy     (888 pairs, pins extract_features)
+  cache_features/*_{raw,clean}_feats.npy + segrigated_samples/<class>/   (pins the classify step)
+  output_results/metrics_summary.csv, confusion_after_MLP.csv           (evidence for the re-fit)
+
+Outputs (all under tests/golden/):
+  validate_888.json        oracle vs all 888 pairs (max |diff| per block, per-clip worst cases)
+  ref_pairs/NN.wav, NN.npy the shortest N real pairs; travels to the GPU box
+  classifier_after.npz     StandardScaler + MLP(128,64) re-fit exactly as pipeline1.py:462-531 does,
+                           with the 905x149 feature matrix and expected predict / predict_proba
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import dysf_oracle as O  # noqa: E402
+
+REF = os.environ.get("DYSF_REFERENCE", "/root/reference")
+N_PAIRS = 12
+CONFIG1_CLIP = "F_0050_10y9m_1 (mp3cut.net)10.wav"
+AUDIO_EXTS = (".wav", ".mp3", ".flac", ".m4a", ".ogg")  # pipeline1.py:77
+
+
+def validate_all():
+    wavs = sorted(glob.glob(os.path.join(REF, "clear_audio", "*.wav")))
+    blocks = {"mfcc_stats": (0, 40), "delta_stats": (40, 80), "delta2_stats": (80, 120),
+              "chroma_stats": (120, 144), "text": (144, 149)}
+    bmax = {k: 0.0 for k in blocks}
+    rows, lengths = [], {}
+    for w in wavs:
+        stem = os.path.basename(w)[:-4]
+        g = os.path.join(REF, "cache_features", stem + "_clean_feats.npy")
+        if not os.path.exists(g):
+            continue
+        pcm, sr = O.read_wav_pcm16(w)
+        feats = O.extract_features(O.pcm16_to_float(pcm), sr)
+        gold = np.load(g)
+        assert gold.dtype == np.float32 and gold.shape == (149,)
+        d = np.abs(feats.astype(np.float64) - gold.astype(np.float64))
+        for k, (a, b) in blocks.items():
+            bmax[k] = max(bmax[k], float(d[a:b].max()))
+        rows.append((stem, float(d.max()), int(d.argmax()), len(pcm)))
+        lengths[w] = len(pcm)
+    diffs = np.array([r[1] for r in rows])
+    rec = {
+        "what": "oracle/dysf_oracle.py extract_features vs reference cache_features/*_clean_feats.npy",
+        "n_pairs": len(rows),
+        "max_abs_diff": float(diffs.max()),
+        "p99_abs_diff": float(np.percentile(diffs, 99)),
+        "median_abs_diff": float(np.median(diffs)),
+        "n_over_1e-4": int((diffs > 1e-4).sum()),
+        "block_max_abs_diff": bmax,
+        "worst_clips": [dict(stem=r[0], max_abs_diff=r[1], index=r[2], n_samples=r[3])
+                        for r in sorted(rows, key=lambda r: -r[1])[:5]],
+        "numpy": np.__version__,
+    }
+    import scipy
+    rec["scipy"] = scipy.__version__
+    with open(os.path.join(HERE, "validate_888.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec, indent=1))
+    return lengths
+
+
+def copy_pairs(lengths):
+    out = os.path.join(HERE, "ref_pairs")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    chosen = sorted(lengths, key=lambda w: (lengths[w], w))[:N_PAIRS]
+    # plus the 3 s-class clip SURVEY.md section 8d names for BASELINE configs[0]
+    chosen += [w for w in lengths if os.path.basename(w) == CONFIG1_CLIP]
+    index = []
+    for i, w in enumerate(chosen):
+        stem = os.path.basename(w)[:-4]
+        shutil.copyfile(w, os.path.join(out, f"{i:02d}.wav"))
+        shutil.copyfile(os.path.join(REF, "cache_features", stem + "_clean_feats.npy"),
+                        os.path.join(out, f"{i:02d}.npy"))
+        index.append({"id": f"{i:02d}", "reference_stem": stem, "n_samples": lengths[w]})
+    with open(os.path.join(out, "index.json"), "w") as f:
+        json.dump(index, f, indent=1)
+
+
+def list_audio_files(root):  # same walk order as pipeline1.py:91-97
+    files = []
+    for r, _, fs in os.walk(root):
+        for f in fs:
+            if f.lower().endswith(AUDIO_EXTS):
+                files.append(os.path.join(r, f))
+    return sorted(files)
+
+
+def classifier_fixture():
+    from sklearn.metrics import accuracy_score, confusion_matrix, log_loss
+    from sklearn.model_selection import train_test_split
+    from sklearn.neural_network import MLPClassifier
+    from sklearn.preprocessing import LabelEncoder, StandardScaler
+
+    files = list_audio_files(os.path.join(REF, "segrigated_samples"))
+    labels = [os.path.basename(os.path.dirname(f)) for f in files]  # pipeline1.py:358-362
+    X_after = np.vstack([np.load(os.path.join(REF, "cache_features",
+                                              os.path.basename(f).rsplit(".", 1)[0] + "_clean_feats.npy"))
+                         for f in files])
+    le = LabelEncoder()
+    y = le.fit_transform(labels)
+    scaler = StandardScaler().fit(X_after)
+    Xs = scaler.transform(X_after)
+    Xtr, Xte, ytr, yte = train_test_split(Xs, y, test_size=0.2, stratify=y, random_state=42)
+    idx_tr, idx_te = train_test_split(np.arange(len(y)), test_size=0.2, stratify=y, random_state=42)
+    mlp = MLPClassifier(hidden_layer_sizes=(128, 64), max_iter=400, random_state=42)
+    mlp.fit(Xtr, ytr)
+    pred_te = mlp.predict(Xte)
+    acc = float(accuracy_score(yte, pred_te) * 100.0)
+    loss = float(log_loss(yte, mlp.predict_proba(Xte)))
+    cm = confusion_matrix(yte, pred_te)
+    with open(os.path.join(REF, "output_results", "confusion_after_MLP.csv")) as f:
+        ref_cm = np.array([[int(v) for v in row[1:]] for row in list(csv.reader(f))[1:]])
+    evidence = {"accuracy": acc, "log_loss": loss, "confusion": cm.tolist(),
+                "reference_confusion_after_MLP": ref_cm.tolist(),
+                "confusion_matches_reference": bool((cm == ref_cm).all()),
+                "reference_metrics_summary_after_MLP": [69.06077348066299, 1.8513111489493788]}
+    print(json.dumps(evidence, indent=1))
+    np.savez_compressed(
+        os.path.join(HERE, "classifier_after.npz"),
+        X=X_after.astype(np.float32), y=y.astype(np.int64), classes=np.array(le.classes_),
+        mean=scaler.mean_, scale=scaler.scale_,
+        W1=mlp.coefs_[0], b1=mlp.intercepts_[0], W2=mlp.coefs_[1], b2=mlp.intercepts_[1],
+        W3=mlp.coefs_[2], b3=mlp.intercepts_[2],
+        test_index=idx_te.astype(np.int64),
+        expected_pred=mlp.predict(Xs).astype(np.int64), expected_proba=mlp.predict_proba(Xs),
+        evidence=json.dumps(evidence))
+
+
+if __name__ == "__main__":
+    lengths = validate_all()
+    copy_pairs(lengths)
+    classifier_fixture()
