@@ -1,0 +1,130 @@
+/*
+ * dysf_hip.h -- C ABI of the MI355X (gfx950) dysfluency feature-extraction library (libdysf_hip.so).
+ *
+ * The reference (kishormb/Recognizing-Speech-Dysfluencies-in-Stuttering) has no FFI: its hot path sits
+ * behind plain Python functions.  Each entry point below names the reference interface it replaces;
+ * the Python binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ *   reference interface                                      replaced by
+ *   -------------------------------------------------------  ----------------------------------------
+ *   module constants TARGET_SR / MFCC_N   pipeline1.py:77-86  DysfParams + dysf_params_preset()
+ *                    N_FFT / HOP_LEN      main.py:621-630
+ *   extract_audio_features(y, sr)         pipeline1.py:206-239 dysf_extract_batch{,_dev}  (pooled rows)
+ *   extract_features(y, sr, transcript)   pipeline1.py:257-265 same + 5 zero text features appended by
+ *                                                              the caller (transcript is always "")
+ *   load_audio() on PCM_16 WAV            pipeline1.py:100-106 int16 PCM accepted directly (x/32768)
+ *   "except Exception -> zeros" convention pipeline1.py:213-214,237-239  per-clip status codes; non-OK
+ *                                                              clips produce an all-zero row
+ *   librosa.estimate_tuning (inside chroma_stft, p1:227)      optional per-clip tuning index output
+ *
+ * Conventions: every function returns 0 on success or a negative DYSF_E_* code and never throws;
+ * dysf_last_error() returns a thread-local message for the last failure.  The library never retains
+ * or frees caller buffers.  A handle owns its device tables and workspace and must not be used from
+ * two threads at once; use one handle per GPU / stream.
+ */
+#ifndef DYSF_HIP_H
+#define DYSF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYSF_ABI_VERSION 1
+
+/* per-clip status (int32) */
+#define DYSF_OK            0
+#define DYSF_TOO_SHORT     1 /* fewer than delta_width frames: librosa.feature.delta raises (p1:217)   */
+#define DYSF_NONFINITE     2 /* NaN/Inf sample: librosa.util.valid_audio raises                         */
+#define DYSF_EMPTY         3 /* zero-length clip                                                        */
+
+/* function return codes */
+#define DYSF_E_INVALID    (-1) /* bad argument / unsupported parameter combination */
+#define DYSF_E_HIP        (-2) /* a HIP runtime call failed (message has the HIP error string) */
+#define DYSF_E_NOMEM      (-3)
+
+/* PCM element types */
+#define DYSF_PCM_I16 0 /* int16, scaled by 1/32768 on the fly (soundfile / librosa.load semantics) */
+#define DYSF_PCM_F32 1 /* float32 in [-1, 1) exactly as the reference passes `y` */
+
+typedef struct DysfParams {
+  int32_t sr;          /* sample rate the clips are at (no resampling on this path)            */
+  int32_t n_fft;       /* 256, 512, 1024 or 2048                                               */
+  int32_t hop;         /* hop length in samples                                                */
+  int32_t n_mels;      /* Slaney mel bands, <= 128                                             */
+  int32_t n_mfcc;      /* DCT-II (ortho) rows kept, <= 48                                      */
+  float   fmin;        /* mel lower edge (Hz)                                                  */
+  float   fmax;        /* mel upper edge (Hz); <= 0 means sr / 2                               */
+  float   top_db;      /* power_to_db clamp below the clip-global max; < 0 disables the clamp  */
+  float   amin;        /* power_to_db floor (1e-10)                                            */
+  int32_t delta_width; /* must be 9 (librosa default; the only width the reference uses)       */
+  int32_t chroma;      /* 1: append chroma_stft mean/std (12 + 12) to the pooled row           */
+  int32_t reserved[5];
+} DysfParams;
+
+#define DYSF_PRESET_REFERENCE_149 0 /* pipeline1.py / main1.py: 2048/512/128 mel/20 mfcc + chroma      */
+#define DYSF_PRESET_BENCH_512     1 /* BASELINE.json configs[1]: 512/160/64 mel/40 mfcc, no chroma     */
+
+typedef struct DysfHandle DysfHandle;
+
+int32_t     dysf_abi_version(void);
+const char* dysf_last_error(void);
+
+/* Fill *p with a named preset. */
+int32_t dysf_params_preset(int32_t preset, DysfParams* p);
+
+/* Build all tables (window, FFT twiddles, banded mel pack, DCT pack, 100 chroma banks) in float64 on
+ * the host, round to float32 and upload to `device`.  device < 0 builds host tables only (no HIP
+ * call is made; used by CPU-side table tests).                                                        */
+int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out);
+void    dysf_destroy(DysfHandle* h);
+
+int32_t dysf_pooled_dim(const DysfHandle* h);                   /* 6*n_mfcc (+24 with chroma)      */
+int32_t dysf_frame_rows(const DysfHandle* h);                   /* 3*n_mfcc                         */
+int64_t dysf_num_frames(const DysfHandle* h, int64_t n_samples);/* 1 + n_samples / hop              */
+
+/* Debug / test access to the host copies of the tables.  which: 0 window[n_fft], 1 mel[n_mels*n_bins]
+ * (dense, row-major), 2 dct[n_mfcc*n_mels], 3 chroma bank[12*n_bins] for tuning index `arg` (0..99).
+ * Returns the number of floats written (<= cap) or a negative error.                                  */
+int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float* dst, int64_t cap);
+
+/*
+ * Batched extraction, DEVICE buffers (the hot path; everything stays in HBM).
+ *   d_pcm      concatenated clips, element type pcm_type
+ *   d_offsets  [n_clips + 1] sample offsets into d_pcm (clip i = [off[i], off[i+1]))
+ *   max_samples  an upper bound on the longest clip (host-side sizing of workspace / launch)
+ *   d_pooled   [n_clips, pooled_dim] float32, or NULL
+ *   d_frames   [n_clips, 3*n_mfcc, frame_stride] float32 (MFCC, delta, delta2 rows; columns >= T_i are
+ *              zero-filled), or NULL
+ *   d_status   [n_clips] int32, or NULL
+ *   d_tuning   [n_clips] int32 tuning-histogram index 0..99 (tuning = -0.5 + 0.01*idx), or NULL
+ *   stream     hipStream_t (NULL = default stream).  The call only enqueues work.
+ */
+int32_t dysf_extract_batch_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type,
+                               const int64_t* d_offsets, int32_t n_clips, int64_t max_samples,
+                               float* d_pooled, float* d_frames, int64_t frame_stride,
+                               int32_t* d_status, int32_t* d_tuning, void* stream);
+
+/*
+ * Batched extraction, HOST buffers: copies PCM to the device, runs dysf_extract_batch_dev, copies the
+ * requested outputs back and synchronises.  Same argument meaning with host pointers; `offsets` is a
+ * host array.  This is what a per-clip `extract_features(y, sr)` call binds to (n_clips = 1).
+ */
+int32_t dysf_extract_batch(DysfHandle* h, const void* pcm, int32_t pcm_type, const int64_t* offsets,
+                           int32_t n_clips, float* pooled, float* frames, int64_t frame_stride,
+                           int32_t* status, int32_t* tuning);
+
+/* Kernel-level test hook: power spectrogram of one clip, device buffers.
+ * d_S is [T, n_bins] float32 (frame-major).                                                           */
+int32_t dysf_debug_stft_power_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, int64_t n_samples,
+                                  float* d_S, void* stream);
+
+/* Same for the un-clamped log-mel spectrogram (10*log10(max(amin, mel))); d_logmel is [T, n_mels]. */
+int32_t dysf_debug_logmel_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, int64_t n_samples,
+                              float* d_logmel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYSF_HIP_H */

@@ -1,0 +1,77 @@
+"""Classifier heads (PyTorch-ROCm; the only part of the path that is not hand-written HIP).
+
+MLPHead reproduces the inference half of the reference's classify step -- ``StandardScaler.transform`` followed
+by ``MLPClassifier(hidden_layer_sizes=(128, 64)).predict / predict_proba`` (pipeline1.py:470-473, 497, 512-514;
+single-clip form main1.py:987-990) -- from exported arrays.  Training stays scikit-learn on CPU (out of scope).
+CNNHead is the benchmark-only 2-layer CNN of BASELINE.json configs[2]; the reference has no CNN.
+"""
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MLPHead(nn.Module):
+    """(x - mean_) / scale_  ->  relu(x W1 + b1) -> relu(. W2 + b2) -> . W3 + b3  (logits); softmax for proba."""
+
+    def __init__(self, mean, scale, weights: Sequence[np.ndarray], biases: Sequence[np.ndarray], classes=None,
+                 dtype=torch.float32):
+        super().__init__()
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(dtype)  # noqa: E731
+        self.register_buffer("mean", t(mean))
+        self.register_buffer("inv_scale", t(1.0 / np.asarray(scale, dtype=np.float64)))
+        self.weights = nn.ParameterList([nn.Parameter(t(w), requires_grad=False) for w in weights])
+        self.biases = nn.ParameterList([nn.Parameter(t(b), requires_grad=False) for b in biases])
+        self.classes = None if classes is None else [str(c) for c in classes]
+        self.n_features_in_ = int(np.asarray(mean).shape[0])
+
+    @classmethod
+    def from_npz(cls, path: str, dtype=torch.float32) -> "MLPHead":
+        z = np.load(path, allow_pickle=False)
+        return cls(z["mean"], z["scale"], [z["W1"], z["W2"], z["W3"]], [z["b1"], z["b2"], z["b3"]],
+                   classes=z["classes"], dtype=dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[-1] != self.n_features_in_:  # the guard of main1.py:976-981
+            raise ValueError(f"Feature mismatch! Expected {self.n_features_in_}, got {x.shape[-1]}.")
+        h = (x.to(self.mean.dtype) - self.mean) * self.inv_scale
+        n = len(self.weights)
+        for i in range(n):
+            h = torch.addmm(self.biases[i], h, self.weights[i])
+            if i + 1 < n:
+                h = F.relu(h)
+        return h
+
+    @torch.no_grad()
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.softmax(self.forward(x), dim=-1)
+
+    @torch.no_grad()
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.argmax(self.forward(x), dim=-1)
+
+    def inverse_transform(self, idx) -> list:
+        """LabelEncoder.inverse_transform (pipeline1.py:462-465; classes are the sorted folder names)."""
+        return [self.classes[int(i)] for i in idx]
+
+
+class CNNHead(nn.Module):
+    """Conv2d(1->32,3x3,p1) ReLU MaxPool2 Conv2d(32->64,3x3,p1) ReLU global-avg-pool Linear(64->3) on
+    [B, 1, 3*n_mfcc, T] frame-level features; random weights from ``torch.manual_seed(seed)``."""
+
+    def __init__(self, n_classes: int = 3, seed: int = 0):
+        super().__init__()
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.conv1 = nn.Conv2d(1, 32, 3, padding=1)
+        self.conv2 = nn.Conv2d(32, 64, 3, padding=1)
+        self.fc = nn.Linear(64, n_classes)
+        torch.random.set_rng_state(g)
+
+    def forward(self, frames: torch.Tensor) -> torch.Tensor:
+        x = frames.unsqueeze(1) if frames.dim() == 3 else frames
+        x = F.max_pool2d(F.relu(self.conv1(x)), 2)
+        x = F.relu(self.conv2(x))
+        return self.fc(x.mean(dim=(2, 3)))

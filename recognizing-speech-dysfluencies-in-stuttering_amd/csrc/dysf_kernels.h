@@ -1,0 +1,56 @@
+// dysf_kernels.h -- argument block shared by the C ABI (dysf_capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dysf_hip.h"
+
+namespace dysf {
+
+struct KArgs {
+  // input
+  const void* pcm;
+  const long long* offsets;
+  int n_clips;
+  // outputs (any may be null)
+  float* pooled;
+  int pooled_dim;
+  float* frames;
+  long long frame_stride;
+  int* status;
+  int* tuning;
+  float* dbg_S;       // [T][n_bins] of clip 0 (single-clip debug launches only)
+  float* dbg_logmel;  // [T][n_mels]
+  // parameters
+  int sr, hop, kpad, n_mels, mp, n_mfcc;
+  float top_db, amin;
+  int chroma;
+  int rstride;  // floats per wave region (FFT exchange + power-spectrum rows)
+  // tables
+  const float* window;
+  const float* stage_tw;
+  const float* post_tw;
+  const float* mel_pack;
+  const int* mel_meta;
+  int mel_rb;
+  const double* dct_pack;  // float64 A operands
+  int dct_rb, dct_steps;
+  const float* chroma_pack;
+  int chroma_steps;
+  int pip_kmin, pip_kmax;
+  // per-workgroup global workspace
+  float* ws_logmel;
+  long long ws_logmel_stride;
+  float* ws_peak_mag;
+  int* ws_peak_bin;
+  long long ws_peak_stride;
+  // LDS carve-up (float offsets)
+  int lds_region, lds_pcm, lds_logmel, lds_misc;
+};
+
+constexpr int kKernelThreads = 512;
+
+hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
+                              hipStream_t s);
+
+}  // namespace dysf

@@ -1,0 +1,610 @@
+// dysf_kernels.hip -- gfx950 kernels for the dysfluency feature path.
+//
+// One persistent 512-thread workgroup per clip runs the whole of
+//   librosa.feature.mfcc -> delta -> delta(order=2) -> stat_pair  (+ chroma_stft)   pipeline1.py:216-228
+// without leaving the CU:
+//   phase A  per tile of frames: coalesced PCM -> LDS tile; per-wave register FFT (dysf_fft.hpp) ->
+//            power spectrum tile in LDS; banded Slaney-mel GEMM on v_mfma_f32_16x16x4_f32; 10*log10 ->
+//            log-mel [T][n_mels] kept in LDS (global workspace only when a clip is too long);
+//            optional piptrack peak picking for the tuning estimate
+//   phase B  clip-global top_db clamp, DCT-II on the float64 MFMA, Savitzky-Golay deltas, frame-level rows
+//            [3*n_mfcc][T] and pooled mean/std (float64 accumulators)
+//   phase C  (chroma only) median / histogram tuning decision, second STFT pass, chroma GEMM on MFMA
+//            against the selected one of 100 banks, per-frame max normalisation, mean/std
+#include <hip/hip_runtime.h>
+
+#include "dysf_fft.hpp"
+#include "dysf_kernels.h"
+
+namespace dysf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kChunk = 64;       // output frames per phase-B chunk
+constexpr int kChunkCols = 80;   // DCT columns per chunk (64 + 8 halo each side)
+constexpr int kChunkStride = 81; // LDS row stride of the MFCC chunk
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in order; this only stops the compiler from reordering them.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCM tile staging: samples [s0, s0 + count) of the clip (zero outside [0, n)) -> LDS as float32.
+// int16 is loaded as aligned 32-bit pairs; the 1/32768 scale is exact.
+// Returns true if this thread saw a non-finite sample (float input only).
+template <int PCM>
+__device__ __forceinline__ bool stage_pcm(const void* pcm, long long off, long long n, long long s0, int count,
+                                          float* tile) {
+  bool bad = false;
+  if (PCM == DYSF_PCM_I16) {
+    const short* base = (const short*)pcm;
+    const long long a0 = (off + s0) & ~1LL;  // even element index (floor, also for negatives)
+    const int npairs = (int)(((off + s0 + count) - a0 + 1) >> 1);
+    for (int j = threadIdx.x; j < npairs; j += kThreads) {
+      const long long a = a0 + 2LL * j;
+      const bool v0 = (a >= off) && (a < off + n);
+      const bool v1 = (a + 1 >= off) && (a + 1 < off + n);
+      float f0 = 0.f, f1 = 0.f;
+      if (v0 && v1) {
+        const int w = *(const int*)(base + a);
+        f0 = (float)(short)(w & 0xffff) * (1.0f / 32768.0f);
+        f1 = (float)(w >> 16) * (1.0f / 32768.0f);
+      } else {
+        if (v0) f0 = (float)base[a] * (1.0f / 32768.0f);
+        if (v1) f1 = (float)base[a + 1] * (1.0f / 32768.0f);
+      }
+      const long long i0 = a - (off + s0);
+      if (i0 >= 0 && i0 < count) tile[i0] = f0;
+      if (i0 + 1 >= 0 && i0 + 1 < count) tile[i0 + 1] = f1;
+    }
+  } else {
+    const float* base = (const float*)pcm;
+    for (int j = threadIdx.x; j < count; j += kThreads) {
+      const long long s = s0 + j;
+      float f = 0.f;
+      if (s >= 0 && s < n) {
+        f = base[off + s];
+        bad |= !isfinite(f);
+      }
+      tile[j] = f;
+    }
+  }
+  return bad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane constants of the wave FFT, loaded once per kernel.
+template <int NC>
+struct FftConsts {
+  float win_e[kPts], win_o[kPts];  // window at samples 2n, 2n+1, n = ls + L*p
+  float t1r[kPts], t1i[kPts];      // stage-1 twiddles
+};
+
+template <int NC>
+__device__ __forceinline__ void load_fft_consts(FftConsts<NC>& c, const KArgs& a, int ls) {
+  constexpr int L = FftGeom<NC>::L;
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    const int n = ls + L * p;
+    c.win_e[p] = a.window[2 * n];
+    c.win_o[p] = a.window[2 * n + 1];
+    c.t1r[p] = a.stage_tw[(ls * kPts + p) * 2];
+    c.t1i[p] = a.stage_tw[(ls * kPts + p) * 2 + 1];
+  }
+}
+
+// Two-pass (re, then im) transpose of a lane's 16 points through the frame's exchange buffer.
+template <int NC, int SPREV>
+__device__ __forceinline__ void fft_exchange(float* re, float* im, float* xb, int ls) {
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = re[p];
+  wave_lds_sync();
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) re[p] = xb[pad_idx(fft_in_index<NC>(ls, p))];
+  wave_lds_sync();
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = im[p];
+  wave_lds_sync();
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) im[p] = xb[pad_idx(fft_in_index<NC>(ls, p))];
+  wave_lds_sync();
+}
+
+// Windowed frame (in the LDS PCM tile at float offset frame_off) -> power spectrum row srow[0..NC].
+// xb and srow both live in the calling wave's private LDS region.
+template <int NC>
+__device__ __forceinline__ void wave_frame_power(const float* tile, int frame_off, float* xb, float* srow,
+                                                 int ls, const FftConsts<NC>& c, const KArgs& a) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L;
+  constexpr int LAST = G::NSTAGE - 1;
+  float re[kPts], im[kPts];
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    const int n = ls + L * p;
+    re[p] = tile[frame_off + 2 * n] * c.win_e[p];
+    im[p] = tile[frame_off + 2 * n + 1] * c.win_o[p];
+  }
+  fft_stage<NC, 0>(re, im, nullptr, nullptr);
+  fft_exchange<NC, 0>(re, im, xb, ls);
+  fft_stage<NC, 1>(re, im, c.t1r, c.t1i);
+  if (G::NSTAGE == 3) {
+    fft_exchange<NC, 1>(re, im, xb, ls);
+    float t2r[kPts], t2i[kPts];
+    const float* tw2 = a.stage_tw + (size_t)L * kPts * 2;
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) {
+      t2r[p] = tw2[(ls * kPts + p) * 2];
+      t2i[p] = tw2[(ls * kPts + p) * 2 + 1];
+    }
+    fft_stage<NC, 2>(re, im, t2r, t2i);
+  }
+  // natural-order spectrum through the buffer; gather the (k, NC-k) pairs this lane un-packs
+  float zkr[9], zki[9], zmr[9], zmi[9];
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = re[p];
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = (i == 8) ? NC / 2 : ls + L * i;
+    zkr[i] = xb[pad_idx(k)];
+    zmr[i] = xb[pad_idx((NC - k) % NC)];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = im[p];
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = (i == 8) ? NC / 2 : ls + L * i;
+    zki[i] = xb[pad_idx(k)];
+    zmi[i] = xb[pad_idx((NC - k) % NC)];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = (i == 8) ? NC / 2 : ls + L * i;
+    const float wr = a.post_tw[2 * k], wi = a.post_tw[2 * k + 1];
+    float pk, pm;
+    rfft_pair_power(zkr[i], zki[i], zmr[i], zmi[i], wr, wi, &pk, &pm);
+    if (i < 8 || ls == 0) {
+      srow[k] = pk;
+      srow[NC - k] = pm;
+    }
+  }
+  wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// piptrack on one power-spectrum row (the wave's own frame): append (mag, histogram bin) of every
+// local maximum above 0.1*max in [pip_kmin, pip_kmax) to the workgroup's peak list.
+template <int NC>
+__device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool frame_valid, const KArgs& a,
+                                            float* peak_mag, int* peak_bin, int* peak_count, int peak_cap) {
+  constexpr int L = FftGeom<NC>::L;
+  float mx = 0.f;
+  for (int k = ls; k <= NC; k += L) mx = fmaxf(mx, srow[k]);
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float ref = __fmul_rn(0.1f, mx);
+  const int lane = threadIdx.x & 63;
+  const int span = a.pip_kmax - a.pip_kmin;
+  for (int kk = 0; kk < span; kk += L) {  // uniform trip count across the wave
+    const int k = a.pip_kmin + kk + ls;
+    bool is_peak = false;
+    float x0 = 0.f, xm = 0.f, x1 = 0.f;
+    if (frame_valid && k < a.pip_kmax) {
+      x0 = srow[k]; xm = srow[k - 1]; x1 = srow[k + 1];
+      const float z0 = x0 > ref ? x0 : 0.f, zm = xm > ref ? xm : 0.f, z1 = x1 > ref ? x1 : 0.f;
+      is_peak = (z0 > zm) && (z0 >= z1);
+    }
+    const unsigned long long mask = __ballot(is_peak);
+    if (mask == 0ull) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(peak_count, __popcll(mask));
+    base = __shfl(base, 0);
+    if (is_peak) {
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      // numba-typed parabolic interpolation of librosa.piptrack (int literals promote to float64)
+      const float dsum = __fadd_rn(x1, xm), ddif = __fsub_rn(x1, xm);
+      const double pa = (double)dsum - 2.0 * (double)x0;
+      const double pb = (double)ddif / 2.0;
+      const float shift = (fabs(pb) >= fabs(pa)) ? 0.f : (float)(-pb / pa);
+      const float avg = __fmul_rn(ddif, 0.5f);
+      const float mag = __fadd_rn(x0, __fmul_rn(__fmul_rn(0.5f, avg), shift));
+      const float pitch = (float)((((double)k + (double)shift) * (double)a.sr) / (double)(2 * NC));
+      // pitch_tuning residual, float32 like numpy; log2 is correctly rounded via float64
+      const float octs = (float)log2((double)__fdiv_rn(pitch, 27.5f));
+      const float x12 = __fmul_rn(12.0f, octs);
+      float r = x12 - floorf(x12);
+      if (r >= 0.5f) r = __fsub_rn(r, 1.0f);
+      const double rd = (double)r;
+      int b = (int)floor((rd + 0.5) * 100.0);
+      b = b < 0 ? 0 : (b > 99 ? 99 : b);
+      while (b > 0 && rd < __dadd_rn(__dmul_rn((double)b, 0.01), -0.5)) --b;
+      while (b < 99 && rd >= __dadd_rn(__dmul_rn((double)(b + 1), 0.01), -0.5)) ++b;
+      if (slot < peak_cap) { peak_mag[slot] = mag; peak_bin[slot] = b; }
+    }
+  }
+}
+
+// r-th smallest (0-based) of the n positive floats in v, by bitwise binary search; all threads call.
+__device__ float block_select(const float* v, int n, int r, int* scratch) {
+  unsigned prefix = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = prefix | (1u << bit);
+    if (threadIdx.x == 0) *scratch = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += kThreads) cnt += (__float_as_uint(v[i]) < cand) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(scratch, cnt);
+    __syncthreads();
+    if (*scratch <= r) prefix = cand;
+    __syncthreads();
+  }
+  return __uint_as_float(prefix);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NC, int PCM, bool LM_LDS>
+__global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L, FPW = G::FPW;
+  constexpr int FPI = FPW * kWaves;  // frames per tile
+  extern __shared__ __align__(16) float lds[];
+  float* regions = lds + a.lds_region;
+  float* tile = lds + a.lds_pcm;
+  float* lm_lds = lds + a.lds_logmel;
+  float* misc = lds + a.lds_misc;
+  // misc layout (floats): [0..7] wave max, [8] bad flag (int), [9] peak count (int), [10] scratch (int),
+  // [16..115] histogram (int), [128..] chroma partial sums
+  int* imisc = (int*)misc;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane / L, ls = lane % L;
+  float* wregion = regions + wave * a.rstride;
+  float* xb = wregion + q * G::XSTRIDE;
+  float* srow_own = wregion + q * a.kpad;
+
+  const int C = a.n_mfcc;
+  for (int clip = blockIdx.x; clip < a.n_clips; clip += gridDim.x) {
+    const long long off = a.offsets[clip];
+    const long long n = a.offsets[clip + 1] - off;
+    const int T = (int)(1 + n / a.hop);
+    int st = DYSF_OK;
+    if (n <= 0) st = DYSF_EMPTY;
+    else if (T < 9) st = DYSF_TOO_SHORT;
+    float* lm = LM_LDS ? lm_lds : (a.ws_logmel + (size_t)blockIdx.x * a.ws_logmel_stride);
+    float* pk_mag = a.ws_peak_mag ? a.ws_peak_mag + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
+    int* pk_bin = a.ws_peak_bin ? a.ws_peak_bin + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
+    if (tid < 16) imisc[tid] = 0;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ phase A
+    float lmax = -INFINITY;
+    bool bad = false;
+    const int ntiles = (st == DYSF_OK) ? (T + FPI - 1) / FPI : 0;
+    const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+    {
+    FftConsts<NC> fc;
+    load_fft_consts<NC>(fc, a, ls);
+    for (int ti = 0; ti < ntiles; ++ti) {
+      const int f0 = ti * FPI;
+      bad |= stage_pcm<PCM>(a.pcm, off, n, (long long)f0 * a.hop - NC, tile_samples, tile);
+      __syncthreads();
+      {
+        const int fl = wave * FPW + q;  // frame within tile
+        wave_frame_power<NC>(tile, fl * a.hop, xb, srow_own, ls, fc, a);
+        if (a.chroma)
+          frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[9], (int)a.ws_peak_stride);
+      }
+      __syncthreads();
+      if (a.dbg_S) {
+        for (int i = tid; i < FPI * (NC + 1); i += kThreads) {
+          const int f = i / (NC + 1), k = i % (NC + 1);
+          if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
+        }
+      }
+      // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16]
+      constexpr int CB = (FPI + 15) / 16;
+      for (int t16 = wave; t16 < a.mel_rb * CB; t16 += kWaves) {
+        const int rb = t16 / CB, cb = t16 % CB;
+        const int kbeg = a.mel_meta[rb * 3], nst = a.mel_meta[rb * 3 + 1], poff = a.mel_meta[rb * 3 + 2];
+        int f = cb * 16 + (lane & 15);
+        const bool fvalid = f < FPI;
+        f = fvalid ? f : FPI - 1;
+        const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
+        const float* wp = a.mel_pack + poff + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int kl = kbeg + (lane >> 4);
+        for (int s = 0; s < nst; ++s) {
+          const int k = kl + 4 * s;
+          const float bv = (k <= NC) ? srow[k] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s * 64], bv, acc, 0, 0, 0);
+        }
+        const int t = f0 + f;
+        if (fvalid && t < T) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = rb * 16 + 4 * (lane >> 4) + r;
+            if (m < a.n_mels) {
+              const float v = 10.0f * log10f(fmaxf(a.amin, acc[r]));
+              lm[(size_t)t * a.mp + m] = v;
+              lmax = fmaxf(lmax, v);
+            }
+          }
+        }
+      }
+      // next iteration's staging barrier orders these S reads before the next FFT's LDS writes
+    }
+    }
+    if (PCM == DYSF_PCM_F32 && st == DYSF_OK) {
+      // samples no frame touches (hop > n_fft/2 + 1) still invalidate the clip in librosa
+      for (long long s = tid; s < n; s += kThreads) bad |= !isfinite(((const float*)a.pcm)[off + s]);
+      if (bad) imisc[8] = 1;
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) misc[wave] = lmax;
+    __syncthreads();
+    if (PCM == DYSF_PCM_F32 && imisc[8]) st = DYSF_NONFINITE;
+    float clip_max = misc[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) clip_max = fmaxf(clip_max, misc[w]);
+    const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
+
+    if (a.dbg_logmel && st == DYSF_OK)
+      for (int i = tid; i < T * a.n_mels; i += kThreads)
+        a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.mp + (i % a.n_mels)];
+
+    float* prow = a.pooled ? a.pooled + (size_t)clip * a.pooled_dim : nullptr;
+    float* frow = a.frames ? a.frames + (size_t)clip * 3 * C * a.frame_stride : nullptr;
+    if (tid == 0 && a.status) a.status[clip] = st;
+
+    if (st != DYSF_OK) {  // the reference's "except -> zeros" row (pipeline1.py:237-239)
+      if (prow) for (int i = tid; i < a.pooled_dim; i += kThreads) prow[i] = 0.f;
+      if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += kThreads) frow[i] = 0.f;
+      if (tid == 0 && a.tuning) a.tuning[clip] = 50;
+      __syncthreads();
+      continue;
+    }
+
+    // ------------------------------------------------------------------ phase B
+    // rows owned by this wave: c = wave, wave + 8, ...; lane = frame within the chunk
+    constexpr int RPW = 6;  // ceil(48 / 8)
+    double s1[RPW][3], s2[RPW][3];
+    float kshift[RPW][3];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { s1[i][j] = 0.0; s2[i][j] = 0.0; kshift[i][j] = 0.f; }
+    float* chunk = lds;  // aliases regions + PCM tile (phase A is over)
+    const int dct_tiles = a.dct_rb * (kChunkCols / 16);
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+      __syncthreads();
+      for (int t16 = wave; t16 < dct_tiles; t16 += kWaves) {
+        const int rb = t16 / (kChunkCols / 16), cb = t16 % (kChunkCols / 16);
+        int t = t0 - 8 + cb * 16 + (lane & 15);
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        const float* lrow = lm + (size_t)t * a.mp;
+        const double* dp = a.dct_pack + (size_t)rb * a.dct_steps * 64 + lane;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < a.dct_steps; ++s) {
+          const int m = 4 * s + (lane >> 4);
+          const double bv = (m < a.n_mels) ? (double)fmaxf(lrow[m], floor_db) : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dp[s * 64], bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
+          chunk[(rb * 16 + (lane >> 4) + 4 * r) * kChunkStride + cb * 16 + (lane & 15)] = (float)acc[r];
+      }
+      __syncthreads();
+      const int t = t0 + lane;
+      const bool tv = t < T;
+      int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
+      tc = tv ? tc : 4;
+      const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
+      const int bc = tc - (t0 - 8);             // column of the delta centre
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int c = wave + i * kWaves;
+        if (c < C) {
+          const float* row = chunk + c * kChunkStride;
+          const float x = row[bx];
+          float xc = 0.f, d = 0.f, dd = 0.f;
+          if (tv || t0 == 0) {
+            const int cc = (tv ? bc : 4 + 8);
+            xc = row[cc];
+            const float p1 = row[cc + 1], m1 = row[cc - 1], p2 = row[cc + 2], m2 = row[cc - 2];
+            const float p3 = row[cc + 3], m3 = row[cc - 3], p4 = row[cc + 4], m4 = row[cc - 4];
+            d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) / 60.f;
+            dd = (28.f * ((p4 - xc) + (m4 - xc)) + 7.f * ((p3 - xc) + (m3 - xc)) - 8.f * ((p2 - xc) + (m2 - xc)) -
+                  17.f * ((p1 - xc) + (m1 - xc))) / 462.f;
+          }
+          if (t0 == 0) {  // shift values = the features of frame 0 (lane 0 of the first chunk)
+            kshift[i][0] = __shfl(x, 0); kshift[i][1] = __shfl(d, 0); kshift[i][2] = __shfl(dd, 0);
+          }
+          if (tv) {
+            const double e0 = (double)x - (double)kshift[i][0];
+            const double e1 = (double)d - (double)kshift[i][1];
+            const double e2 = (double)dd - (double)kshift[i][2];
+            s1[i][0] += e0; s2[i][0] += e0 * e0;
+            s1[i][1] += e1; s2[i][1] += e1 * e1;
+            s1[i][2] += e2; s2[i][2] += e2 * e2;
+            if (frow) {
+              frow[(size_t)c * a.frame_stride + t] = x;
+              frow[(size_t)(C + c) * a.frame_stride + t] = d;
+              frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
+            }
+          }
+        }
+      }
+    }
+    if (frow && a.frame_stride > T) {  // zero-fill the padding columns
+      const int padc = (int)(a.frame_stride - T);
+      for (int i = tid; i < 3 * C * padc; i += kThreads) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
+    }
+    if (prow) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int c = wave + i * kWaves;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double m1 = wave_sum(s1[i][j]) / (double)T;
+          const double m2 = wave_sum(s2[i][j]) / (double)T;
+          if (c < C && lane == 0) {
+            const double var = m2 - m1 * m1;
+            prow[j * 2 * C + c] = (float)((double)kshift[i][j] + m1);
+            prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ phase C: chroma
+    if (a.chroma) {
+      int* hist = imisc + 16;
+      int npk = imisc[9];
+      npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
+      int tune = 50;
+      if (npk > 0) {
+        float thr;
+        if (npk & 1) {
+          thr = block_select(pk_mag, npk, npk / 2, &imisc[10]);
+        } else {
+          const float lo = block_select(pk_mag, npk, npk / 2 - 1, &imisc[10]);
+          const float hi = block_select(pk_mag, npk, npk / 2, &imisc[10]);
+          thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+        }
+        if (tid < kTunings) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < npk; i += kThreads)
+          if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
+        __syncthreads();
+        int best = 0, bc = hist[0];
+        for (int i = 1; i < kTunings; ++i)
+          if (hist[i] > bc) { bc = hist[i]; best = i; }
+        tune = best;
+      }
+      if (tid == 0 && a.tuning) a.tuning[clip] = tune;
+      __syncthreads();
+
+      // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the 8 waves)
+      constexpr int CB = (FPI + 15) / 16;
+      float* part = misc + 128;             // [kWaves][CB][16 rows][16 cols]
+      float* raw = part + kWaves * CB * 256;  // [16][CB*16]
+      const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
+      double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c
+      float cshift = 0.f;
+      FftConsts<NC> fc;
+      load_fft_consts<NC>(fc, a, ls);
+      for (int ti = 0; ti < ntiles; ++ti) {
+        const int f0 = ti * FPI;
+        stage_pcm<PCM>(a.pcm, off, n, (long long)f0 * a.hop - NC, tile_samples, tile);
+        __syncthreads();
+        wave_frame_power<NC>(tile, (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a);
+        __syncthreads();
+        const int sb = (a.chroma_steps * wave) / kWaves, se = (a.chroma_steps * (wave + 1)) / kWaves;
+        for (int cb = 0; cb < CB; ++cb) {
+          int f = cb * 16 + (lane & 15);
+          f = f < FPI ? f : FPI - 1;
+          const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int s = sb; s < se; ++s) {
+            const int k = 4 * s + (lane >> 4);
+            const float bv = (k <= NC) ? srow[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bank[s * 64 + lane], bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            part[((wave * CB + cb) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        }
+        __syncthreads();
+        for (int i = tid; i < CB * 256; i += kThreads) {
+          const int cb = i / 256, rc = i % 256;
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < kWaves; ++w) v += part[(w * CB + cb) * 256 + rc];
+          raw[(rc / 16) * (CB * 16) + cb * 16 + (rc % 16)] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          // lane c (< 12) walks the tile's frames in order; every lane computes the frame max
+          for (int f = 0; f < FPI && f0 + f < T; ++f) {
+            float mxv = 0.f;
+#pragma unroll
+            for (int c = 0; c < kChroma; ++c) mxv = fmaxf(mxv, fabsf(raw[c * (CB * 16) + f]));
+            const float len = (mxv < 1.17549435e-38f) ? 1.0f : mxv;
+            if (lane < kChroma) {
+              const float v = __fdiv_rn(raw[lane * (CB * 16) + f], len);
+              if (f0 + f == 0) cshift = v;
+              const double e = (double)v - (double)cshift;
+              cs1 += e; cs2 += e * e;
+            }
+          }
+        }
+        // the next staging barrier protects raw/part and the S regions
+      }
+      if (wave == 0 && lane < kChroma && prow) {
+        const double m1 = cs1 / (double)T, m2 = cs2 / (double)T;
+        const double var = m2 - m1 * m1;
+        prow[6 * C + lane] = (float)((double)cshift + m1);
+        prow[6 * C + kChroma + lane] = (float)sqrt(var > 0.0 ? var : 0.0);
+      }
+    } else if (tid == 0 && a.tuning) {
+      a.tuning[clip] = 50;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NC>
+static hipError_t launch_nc(const KArgs& a, int pcm_type, bool lm_lds, int grid, size_t lds_bytes, hipStream_t s) {
+#define DYSF_LAUNCH(PCMT, LM)                                                                             \
+  do {                                                                                                    \
+    auto kern = dysf_clip_kernel<NC, PCMT, LM>;                                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                       (int)lds_bytes);                                                   \
+    if (e != hipSuccess) return e;                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, s, a);                                \
+    return hipGetLastError();                                                                             \
+  } while (0)
+  if (pcm_type == DYSF_PCM_I16) {
+    if (lm_lds) DYSF_LAUNCH(DYSF_PCM_I16, true); else DYSF_LAUNCH(DYSF_PCM_I16, false);
+  } else {
+    if (lm_lds) DYSF_LAUNCH(DYSF_PCM_F32, true); else DYSF_LAUNCH(DYSF_PCM_F32, false);
+  }
+#undef DYSF_LAUNCH
+}
+
+hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
+                              hipStream_t s) {
+  switch (n_fft) {
+    case 256: return launch_nc<128>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 512: return launch_nc<256>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 1024: return launch_nc<512>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 2048: return launch_nc<1024>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace dysf

@@ -1,0 +1,72 @@
+"""Batch driver: the reference's sequential per-file loop (pipeline1.py:447-456) as one sharded, GPU-resident
+pass -- PCM shard -> HIP feature kernel -> classifier head -> logits -- with one process per GPU.
+
+Clips are independent (the clip-global max and the tuning estimate are intra-clip), so ranks take contiguous
+blocks of the clip index space and the only collective is one all-gather of the per-clip logits
+(RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests)."""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rank r owns clips [r*ceil(n/W), min(n, (r+1)*ceil(n/W)))  (SURVEY.md section 8e)."""
+    per = -(-n // world) if world > 0 else n
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def shard_by_samples(lengths: np.ndarray, world: int) -> np.ndarray:
+    """Variable-length clips: contiguous shards balanced by cumulative sample count.  Returns [world+1] bounds."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    csum = np.concatenate([[0], np.cumsum(lengths)])
+    targets = csum[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(csum, targets, side="left")
+    return np.concatenate([[0], cuts, [len(lengths)]]).astype(np.int64)
+
+
+def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """All-gather [n_local, d] row blocks of a shard_range partition into [n_total, d] on every rank."""
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return local
+    per = -(-n_total // world)
+    pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n_total]
+
+
+class DysfluencyPipeline:
+    """extract -> (pooled | frame-level) features -> head -> logits, everything resident on one GPU."""
+
+    def __init__(self, extractor, head: Optional[torch.nn.Module] = None, head_input: str = "pooled"):
+        assert head_input in ("pooled", "frames")
+        self.extractor = extractor
+        self.head = head
+        self.head_input = head_input
+
+    @torch.no_grad()
+    def run_resident(self, pcm: torch.Tensor, offsets: torch.Tensor, max_samples: int):
+        """pcm/offsets already in HBM.  Returns dict with the features and, if a head is set, ``logits``."""
+        want_frames = self.head_input == "frames"
+        res = self.extractor.extract_batch_device(pcm, offsets, max_samples, pooled=not want_frames, frames=want_frames)
+        if self.head is not None:
+            if want_frames:
+                res["logits"] = self.head(res["frames"])
+            else:
+                x = res["pooled"]
+                pad = self.head.n_features_in_ - x.shape[1] if hasattr(self.head, "n_features_in_") else 0
+                if pad > 0:  # the five always-zero text features (pipeline1.py:243-244)
+                    x = torch.cat([x, x.new_zeros((x.shape[0], pad))], dim=1)
+                res["logits"] = self.head(x)
+        return res
+
+    @torch.no_grad()
+    def run_sharded(self, pcm: torch.Tensor, offsets: torch.Tensor, max_samples: int, n_total: int, rank: int, world: int):
+        """This rank's shard (already resident) -> logits, then the single all-gather of [n_local, n_classes]."""
+        res = self.run_resident(pcm, offsets, max_samples)
+        res["all_logits"] = gather_rows(res["logits"], n_total, rank, world)
+        return res

@@ -1,0 +1,251 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs, vs the committed
+reference fixtures, and size-independent properties at the benchmark's full batch size.
+
+Tolerances (stated here, used below):
+  * pooled 149-d / 240-d vectors: 1e-4 absolute (BASELINE.json north_star), checked against the reference's own
+    cached vectors and against the oracle;
+  * power spectrum: 2e-6 of the frame's largest bin (float32 FFT noise; the reference STFT is float64-accurate);
+  * log-mel above the top_db floor and frame-level MFCC/delta rows: 1e-4 + 2e-6*|x| + a floor-noise term (see
+    _frame_tol): MFCC row 0 is ~ -500, where one float32 ulp is already 6e-5 and both sides carry DCT rounding;
+  * integer outputs (status, tuning index) exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import rsd_amd  # noqa: E402
+from oracle import dysf_oracle as O  # noqa: E402
+
+P149, B512 = rsd_amd.REFERENCE_149, rsd_amd.BENCH_512
+OP = {P149: O.REFERENCE_149, B512: O.BENCH_512}
+
+
+@pytest.fixture(scope="module")
+def ex149():
+    return rsd_amd.get_extractor(P149, 0)
+
+
+@pytest.fixture(scope="module")
+def ex512():
+    return rsd_amd.get_extractor(B512, 0)
+
+
+def _pairs(golden_dir):
+    d = os.path.join(golden_dir, "ref_pairs")
+    for e in json.load(open(os.path.join(d, "index.json"))):
+        pcm, sr = O.read_wav_pcm16(os.path.join(d, e["id"] + ".wav"))
+        yield e["id"], pcm, sr, np.load(os.path.join(d, e["id"] + ".npy"))
+
+
+def test_native_library_is_loaded():
+    assert rsd_amd._lib.lib().dysf_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("params", [B512, P149], ids=["fft512", "fft2048"])
+@pytest.mark.parametrize("clip", [0, 5, 127])
+def test_stft_power_vs_oracle(params, clip):
+    ex = rsd_amd.get_extractor(params, 0)
+    y = O.synth_clip(clip, n=24000)
+    S = ex.stft_power(y)
+    ref = O.stft_power(O.pcm16_to_float(y), OP[params]).T
+    assert S.shape == ref.shape
+    scale = ref.max(axis=1, keepdims=True) + 1e-30
+    assert np.abs(S - ref).max() <= 2e-6 * scale.max()
+    assert (np.abs(S - ref) / scale).max() <= 2e-6
+
+
+@pytest.mark.parametrize("params", [B512, P149], ids=["fft512", "fft2048"])
+def test_logmel_vs_oracle(params):
+    ex = rsd_amd.get_extractor(params, 0)
+    y = O.synth_clip(7, n=32000)
+    L = ex.logmel(y)
+    op = OP[params]
+    S = O.stft_power(O.pcm16_to_float(y), op)
+    ref = (np.float32(10.0) * np.log10(np.maximum(np.float32(op.amin), O.mel_filterbank(op) @ S))).T
+    assert L.shape == ref.shape
+    live = ref > ref.max() - 80.0  # cells the top_db clamp keeps
+    assert np.abs(L - ref)[live].max() <= 2e-3  # float32 FFT noise grows towards the -80 dB floor
+    near = ref > ref.max() - 50.0
+    assert np.abs(L - ref)[near].max() <= 1e-4
+
+
+def _frame_tol(ref):
+    return 2e-4 + 2e-6 * np.abs(ref)
+
+
+@pytest.mark.parametrize("n", [48000, 16000, 1600, 51234])
+def test_frames_vs_oracle_bench_preset(ex512, n):
+    y = O.synth_clip(11, n=n)
+    res = ex512.extract_batch([y], frames=True)
+    ref = O.frame_level_stack(O.pcm16_to_float(y), O.BENCH_512)
+    got = res["frames"][0]
+    assert res["status"][0] == 0 and got.shape == ref.shape
+    assert (np.abs(got - ref) <= _frame_tol(ref)).all(), float(np.abs(got - ref).max())
+    pooled_ref = np.hstack([O.stat_pair(ref[:40]), O.stat_pair(ref[40:80]), O.stat_pair(ref[80:])])
+    assert np.abs(res["pooled"][0] - pooled_ref).max() <= 1e-4
+
+
+def test_reference_pairs_pooled_149(golden_dir):
+    """The reference's own known-answer vectors: clear_audio/<stem>.wav -> cache_features/<stem>_clean_feats.npy."""
+    worst = 0.0
+    for cid, pcm, sr, gold in _pairs(golden_dir):
+        y = O.pcm16_to_float(pcm)
+        feats = rsd_amd.extract_features(y, sr)
+        assert feats.dtype == np.float32 and feats.shape == (149,)
+        d = np.abs(feats - gold)
+        worst = max(worst, float(d.max()))
+        assert d[:120].max() <= 1e-4, (cid, float(d[:120].max()), int(d.argmax()))
+        assert d[120:144].max() <= 1e-4, (cid, "chroma", float(d[120:144].max()))
+        assert (feats[144:] == 0).all()
+    print("worst |gpu - reference| over committed pairs:", worst)
+
+
+def test_tuning_index_matches_oracle(ex149, golden_dir):
+    clips, want = [], []
+    for cid, pcm, sr, gold in _pairs(golden_dir):
+        clips.append(pcm)
+        _, dbg = O.estimate_tuning(O.stft_power(O.pcm16_to_float(pcm), O.REFERENCE_149), O.REFERENCE_149)
+        want.append(dbg["index"])
+    for i in range(6):
+        y = O.synth_clip(i, n=30000)
+        clips.append(y)
+        want.append(O.estimate_tuning(O.stft_power(O.pcm16_to_float(y), O.REFERENCE_149), O.REFERENCE_149)[1]["index"])
+    res = ex149.extract_batch(clips, tuning=True)
+    assert res["tuning"].tolist() == want
+
+
+def test_int16_and_float32_inputs_agree(ex149, ex512):
+    y = O.synth_clip(2, n=20000)
+    for ex in (ex149, ex512):
+        a = ex.extract_batch([y], frames=True)
+        b = ex.extract_batch([O.pcm16_to_float(y)], frames=True)
+        assert np.array_equal(a["pooled"], b["pooled"]) and np.array_equal(a["frames"], b["frames"])
+
+
+def test_error_convention_zero_rows(ex149):
+    ok = O.synth_clip(1, n=9000)
+    short = O.synth_clip(1, n=4000)            # T = 8 < 9 -> delta raises in the reference -> zeros
+    nan = O.pcm16_to_float(ok).copy(); nan[1234] = np.nan
+    inf = O.pcm16_to_float(ok).copy(); inf[-1] = np.inf
+    res = ex149.extract_batch([O.pcm16_to_float(ok), O.pcm16_to_float(short), nan, inf, np.zeros(0, np.float32)], frames=True)
+    assert res["status"].tolist() == [0, 1, 2, 2, 3]
+    assert np.abs(res["pooled"][0]).max() > 0
+    for i in (1, 2, 3, 4):
+        assert (res["pooled"][i] == 0).all() and (res["frames"][i] == 0).all()
+    assert (rsd_amd.extract_features(None, None) == 0).all()
+    assert (rsd_amd.extract_features(nan, 16000) == 0).all()
+    with pytest.raises(ValueError):
+        rsd_amd.extract_audio_features(nan, 16000, strict=True)
+
+
+def test_all_zero_clip_matches_spec(ex149):
+    """L == -100 everywhere, mfcc0 = -100*sqrt(128), every std 0, tuning 0.0, chroma 0."""
+    res = ex149.extract_batch([np.zeros(20000, np.int16)], tuning=True)
+    f = res["pooled"][0]
+    assert res["status"][0] == 0 and res["tuning"][0] == 50
+    assert abs(f[0] - (-100.0 * np.sqrt(128.0))) <= 1e-4
+    assert np.abs(f[1:]).max() <= 1e-6
+    want = O.extract_audio_features(np.zeros(20000, np.float32), 16000)
+    assert np.abs(f - want).max() <= 1e-4
+
+
+def test_ragged_batch_equals_single_clip_calls(ex149, ex512):
+    lens = [4096, 5000, 48000, 12345, 30000, 9999]
+    clips = [O.synth_clip(20 + i, n=n) for i, n in enumerate(lens)]
+    for ex in (ex149, ex512):
+        batch = ex.extract_batch(clips, frames=True, tuning=True)
+        for i, c in enumerate(clips):
+            one = ex.extract_batch([c], frames=True, tuning=True)
+            T = ex.params.n_frames(len(c))
+            assert np.array_equal(batch["pooled"][i], one["pooled"][0])
+            assert np.array_equal(batch["frames"][i][:, :T], one["frames"][0])
+            assert (batch["frames"][i][:, T:] == 0).all()
+            assert batch["tuning"][i] == one["tuning"][0]
+
+
+def test_long_clip_uses_global_workspace(ex149, ex512):
+    """Clips whose log-mel does not fit in LDS take the global-workspace variant of the kernel; same numbers."""
+    y = np.concatenate([O.synth_clip(40 + i, n=48000) for i in range(4)])  # 12 s
+    f = O.pcm16_to_float(y)
+    got = ex149.extract_batch([y])["pooled"][0]
+    assert np.abs(got - O.extract_audio_features(f, 16000)).max() <= 1e-4
+    res = ex512.extract_batch([y], frames=True)
+    ref = O.frame_level_stack(f, O.BENCH_512)
+    assert (np.abs(res["frames"][0] - ref) <= _frame_tol(ref)).all()
+
+
+def test_full_batch_properties_bench_config(ex512):
+    """BASELINE configs[1] size: 1024 clips x 48000 samples resident in HBM.  Size-independent checks:
+    rows of identical clips are bit-identical wherever they sit in the batch, a sample of rows matches the
+    oracle, and the pooled row equals the statistics of the frame-level rows."""
+    bank = np.stack([O.synth_clip(i) for i in range(32)])
+    idx = np.arange(1024) % 32
+    pcm = torch.from_numpy(bank[idx].reshape(-1)).cuda()
+    off = torch.arange(0, 1025, dtype=torch.int64, device="cuda") * 48000
+    res = ex512.extract_batch_device(pcm, off, 48000, pooled=True, frames=True)
+    torch.cuda.synchronize()
+    fr, po = res["frames"], res["pooled"]
+    assert fr.shape == (1024, 120, 301) and int(res["status"].abs().sum()) == 0
+    base = fr[:32]
+    for r in range(1, 32):
+        assert torch.equal(fr[r * 32:(r + 1) * 32], base)
+        assert torch.equal(po[r * 32:(r + 1) * 32], po[:32])
+    for j in (0, 13, 31):
+        ref = O.frame_level_stack(O.pcm16_to_float(bank[j]), O.BENCH_512)
+        got = fr[992 + j].cpu().numpy()
+        assert (np.abs(got - ref) <= _frame_tol(ref)).all()
+    f64 = fr.double()
+    mean, std = f64.mean(dim=2), f64.var(dim=2, unbiased=False).sqrt()
+    want = torch.cat([mean[:, :40], std[:, :40], mean[:, 40:80], std[:, 40:80], mean[:, 80:], std[:, 80:]], dim=1)
+    assert float((po.double() - want).abs().max()) <= 1e-4
+
+
+def test_mlp_head_argmax_on_gpu(golden_dir):
+    from rsd_amd.classifier import MLPHead
+    z = np.load(os.path.join(golden_dir, "classifier_after.npz"))
+    head = MLPHead.from_npz(os.path.join(golden_dir, "classifier_after.npz")).cuda()
+    x = torch.from_numpy(z["X"]).cuda()
+    pred = head.predict(x).cpu().numpy()
+    proba = head.predict_proba(x).cpu().numpy()
+    assert np.array_equal(pred, z["expected_pred"])
+    assert np.abs(proba - z["expected_proba"]).max() <= 1e-4
+
+
+def test_fused_pipeline_features_to_logits(golden_dir):
+    """wav -> HIP features -> scaler + MLP on the same GPU: label equals the oracle-features label."""
+    from rsd_amd.classifier import MLPHead
+    from rsd_amd.pipeline import DysfluencyPipeline
+    head = MLPHead.from_npz(os.path.join(golden_dir, "classifier_after.npz")).cuda()
+    pipe = DysfluencyPipeline(rsd_amd.get_extractor(P149, 0), head, "pooled")
+    clips, gold = [], []
+    for cid, pcm, sr, g in _pairs(golden_dir):
+        clips.append(pcm); gold.append(g)
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    off = torch.tensor(np.concatenate([[0], np.cumsum([len(c) for c in clips])]), dtype=torch.int64, device="cuda")
+    res = pipe.run_resident(pcm, off, max(len(c) for c in clips))
+    torch.cuda.synchronize()
+    want = head.predict(torch.from_numpy(np.stack(gold)).cuda())
+    assert torch.equal(res["logits"].argmax(dim=1), want)
+
+
+def test_cnn_head_runs_on_frame_features(ex512):
+    from rsd_amd.classifier import CNNHead
+    from rsd_amd.pipeline import DysfluencyPipeline
+    cnn = CNNHead().cuda()
+    pipe = DysfluencyPipeline(ex512, cnn, "frames")
+    clips = np.stack([O.synth_clip(i) for i in range(8)])
+    pcm = torch.from_numpy(clips.reshape(-1)).cuda()
+    off = torch.arange(0, 9, dtype=torch.int64, device="cuda") * 48000
+    res = pipe.run_resident(pcm, off, 48000)
+    torch.cuda.synchronize()
+    ref_in = torch.from_numpy(np.stack([O.frame_level_stack(O.pcm16_to_float(c), O.BENCH_512) for c in clips]))
+    ref = CNNHead()(ref_in)
+    assert torch.equal(res["logits"].argmax(1).cpu(), ref.argmax(1))
+    assert float((res["logits"].cpu() - ref).abs().max()) <= 1e-3
