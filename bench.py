@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/s of the feature hot path on BASELINE.json configs[1], one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one resident batch: 1024 synthetic 3 s @ 16 kHz int16 clips ->
+512-pt STFT (hop 160) -> 64 Slaney mels -> dB (top_db 80) -> 40 MFCC + delta + delta-delta, written both as
+frame-level rows [1024, 120, 301] fp32 (the CNN input of configs[2]) and as pooled mean/std rows [1024, 240];
+then the pooled rows go through a small MLP head to per-clip logits and, for N > 1, the single collective of the
+path: an RCCL all-gather of the [1024, 3] logits.  Every rank owns its own 1024-clip shard (weak scaling); the
+PCM is already in HBM when the timed region starts.
+
+Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel (HIP-event timed on the
+launch stream) and, at N = 1, a `cpu_baseline` object (the NumPy oracle timed on the host cores on a bounded
+sample of the same clips).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 1024          # clips per GPU per step (BASELINE.json configs[1])
+N_SAMPLES = 48000     # 3 s @ 16 kHz
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def _cpu_worker(clip):
+    from oracle import dysf_oracle as O
+    return O.frame_level_stack(O.pcm16_to_float(clip), O.BENCH_512).shape[1]
+
+
+def cpu_baseline(bank, budget_s=15.0):
+    """Reported baseline only: the CPU oracle (a NumPy/SciPy port of the reference's librosa calls) on a bounded
+    sample of the same clips, one clip per task over all host cores available to this process."""
+    import multiprocessing as mp
+
+    from threadpoolctl import threadpool_limits
+
+    cores = min(16, len(os.sched_getaffinity(0)))  # a one-GPU box's CPU share is 16 cores
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        n1 = 0
+        while n1 < 8 or time.perf_counter() - t0 < 2.0:
+            _cpu_worker(bank[n1 % len(bank)])
+            n1 += 1
+        one = n1 / (time.perf_counter() - t0)
+        sample = int(min(len(bank), max(cores * 4, one * cores * budget_s * 0.5)))
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_cpu_worker, [bank[i] for i in range(min(cores, len(bank)))])  # warm the workers
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, [bank[i % len(bank)] for i in range(sample)], chunksize=4)
+            dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": round(sample / dt, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} clips of the same synthetic bank through oracle/dysf_oracle.py frame_level_stack "
+                      f"(BENCH_512), one clip per task, {cores} processes x 1 BLAS thread",
+            "one_thread_clips_per_s": round(one, 2), "cpu_model": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bank-workers", type=int, default=0,
+                    help="processes generating the synthetic bank (0 = auto; use 1 under rocprofv3 --pmc, which "
+                         "initialises the GPU before main() and must not be followed by a fork)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import rsd_amd
+    from rsd_amd.classifier import MLPHead
+    from rsd_amd.pipeline import gather_rows
+    from rsd_amd.synth import synth_bank
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # host-only work first (process pools fork; keep that ahead of any GPU initialisation):
+    # every rank owns an identical-size shard of the clip index space
+    workers = args.bank_workers or max(1, min(8, len(os.sched_getaffinity(0)) // max(1, world)))
+    bank = synth_bank(BATCH, N_SAMPLES, 16000, workers=workers)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(bank[:256])
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    pcm = torch.from_numpy(bank.reshape(-1)).to(dev)
+    offsets = (torch.arange(0, BATCH + 1, dtype=torch.int64) * N_SAMPLES).to(dev)
+
+    params = rsd_amd.BENCH_512
+    ex = rsd_amd.FeatureExtractor(params, local_rank)
+    T = params.n_frames(N_SAMPLES)
+    rng = np.random.default_rng(0)
+    dims = [ex.pooled_dim, 128, 64, 3]
+    head = MLPHead(np.zeros(dims[0]), np.ones(dims[0]),
+                   [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)],
+                   [np.zeros(dims[i + 1]) for i in range(3)]).to(dev)
+
+    kern_ms = []
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        res = ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
+        if timed:
+            e1.record()
+            kern_ms.append((e0, e1))
+        logits = head(res["pooled"])
+        return gather_rows(logits, BATCH * world, rank, world), res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            all_logits, res = step(True)
+        fence()
+        dt = time.perf_counter() - t0
+    assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (BATCH * world, 3)
+    assert bool(torch.isfinite(res["frames"]).all())
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    kms = sum(a.elapsed_time(b) for a, b in kern_ms) / max(1, len(kern_ms))
+
+    if rank == 0:
+        clips_per_s = BATCH * world * args.steps / dt
+        algo_bytes = BATCH * (2 * N_SAMPLES + 4 * (ex.frame_rows * T + ex.pooled_dim))  # PCM read once + outputs written once
+        achieved = algo_bytes / (kms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "clips/sec (3 s@16 kHz, 40-MFCC) end-to-end",
+            "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 1024 clips x 48000 int16 samples per GPU resident in HBM, "
+                                   "512-pt STFT hop 160, 64 Slaney mels, top_db 80, 40 MFCC + delta + delta2; outputs "
+                                   "frame-level [1024,120,301] fp32 + pooled [1024,240] fp32, then MLP head -> logits "
+                                   "[1024,3] and (N>1) RCCL all-gather of the logits",
+                       "clips_per_gpu": BATCH, "samples_per_clip": N_SAMPLES, "n_fft": 512, "hop": 160,
+                       "n_mels": 64, "n_mfcc": 40, "frames_per_clip": T, "parallelism": f"clip-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "dysf_clip_kernel<256, i16, logmel-in-LDS>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4),
+                         "kernel_clips_per_s": round(BATCH / (kms * 1e-3), 1)},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,7 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
 
 /*
  * Batched extraction, DEVICE buffers (the hot path; everything stays in HBM).
- *   d_pcm      concatenated clips, element type pcm_type
+ *   d_pcm      concatenated clips, element type pcm_type; 16-byte aligned
  *   d_offsets  [n_clips + 1] sample offsets into d_pcm (clip i = [off[i], off[i+1]))
  *   max_samples  an upper bound on the longest clip (host-side sizing of workspace / launch)
  *   d_pooled   [n_clips, pooled_dim] float32, or NULL

@@ -164,7 +164,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   if (n_clips == 0) return 0;
   if (!d_pcm || !d_offsets) return fail(DYSF_E_INVALID, "null input pointer");
   if (pcm_type != DYSF_PCM_I16 && pcm_type != DYSF_PCM_F32) return fail(DYSF_E_INVALID, "bad pcm_type");
-  if (((uintptr_t)d_pcm & 3u) != 0) return fail(DYSF_E_INVALID, "d_pcm must be 4-byte aligned");
+  if (((uintptr_t)d_pcm & 15u) != 0) return fail(DYSF_E_INVALID, "d_pcm must be 16-byte aligned");
   const HostTables& t = h->t;
   const DysfParams& p = t.p;
   const int64_t t_max = 1 + max_samples / p.hop;
@@ -178,12 +178,12 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.pooled = d_pooled; a.pooled_dim = dysf_pooled_dim(h); a.frames = d_frames; a.frame_stride = frame_stride;
   a.status = d_status; a.tuning = d_tuning; a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel;
   a.sr = p.sr; a.hop = p.hop; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
-  a.top_db = p.top_db; a.amin = p.amin; a.chroma = p.chroma ? 1 : 0;
+  a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
   int mp = p.n_mels;
   while (mp % 32 != 2) ++mp;
   a.mp = mp;
   a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
-  a.mel_pack = h->d_mel_pack; a.mel_meta = h->d_mel_meta; a.mel_rb = t.mel_pack.row_blocks;
+  a.mel_pack = h->d_mel_pack; a.mel_meta = h->d_mel_meta; a.mel_rb = t.mel_pack.row_blocks; a.mel_max_steps = t.mel_pack.max_steps;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_steps = t.dct_pack.max_steps;
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
@@ -193,17 +193,29 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   int rstride = std::max(t.FPW * (t.NC + t.NC / 16), t.FPW * t.kpad);
   while (rstride % 32 != 8) ++rstride;
   a.rstride = rstride;
-  const int tile_samples = ((fpi - 1) * p.hop + p.n_fft + 3) & ~3;
+  const int tile_samples = ((fpi - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int cb = (fpi + 15) / 16;
   const int misc = 128 + (p.chroma ? (kKernelThreads / 64) * cb * 256 + 16 * cb * 16 : 0);
   a.lds_region = 0;
   a.lds_pcm = (kKernelThreads / 64) * rstride;
   a.lds_misc = a.lds_pcm + tile_samples;
   a.lds_logmel = a.lds_misc + misc;
+  {  // phase B reuses [0, lds_misc): MFCC chunk first, then the float64 DCT operands if they fit
+    const int chunk_floats = ((t.cpad * 81 + 3) & ~3);
+    const int dct_floats = t.dct_pack.row_blocks * t.dct_pack.max_steps * 64 * 2;
+    a.lds_dct = (chunk_floats + dct_floats <= a.lds_misc) ? chunk_floats : -1;
+  }
   const size_t fixed_bytes = (size_t)a.lds_logmel * 4;
   if (fixed_bytes > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
   const bool lm_lds = fixed_bytes + (size_t)t_max * mp * 4 <= h->lds_limit;
-  const size_t lds_bytes = lm_lds ? fixed_bytes + (size_t)t_max * mp * 4 : fixed_bytes;
+  size_t lds_bytes = lm_lds ? fixed_bytes + (size_t)t_max * mp * 4 : fixed_bytes;
+  // the packed mel taps live in LDS for the whole kernel when there is room left
+  a.mel_pack_floats = (int)t.mel_pack.data.size();
+  a.lds_melpack = -1;
+  if (lds_bytes + (size_t)a.mel_pack_floats * 4 + 16 <= h->lds_limit) {
+    a.lds_melpack = (int)((lds_bytes / 4 + 3) & ~(size_t)3);
+    lds_bytes = ((size_t)a.lds_melpack + a.mel_pack_floats) * 4;
+  }
   const int grid = std::min(n_clips, h->num_cu);
   if (!lm_lds) {
     if (int rc = h->ws_logmel.reserve((size_t)grid * t_max * mp * 4)) return rc;

@@ -23,7 +23,7 @@ struct KArgs {
   float* dbg_logmel;  // [T][n_mels]
   // parameters
   int sr, hop, kpad, n_mels, mp, n_mfcc;
-  float top_db, amin;
+  float top_db, amin, db_amin;
   int chroma;
   int rstride;  // floats per wave region (FFT exchange + power-spectrum rows)
   // tables
@@ -32,7 +32,7 @@ struct KArgs {
   const float* post_tw;
   const float* mel_pack;
   const int* mel_meta;
-  int mel_rb;
+  int mel_rb, mel_max_steps;
   const double* dct_pack;  // float64 A operands
   int dct_rb, dct_steps;
   const float* chroma_pack;
@@ -46,6 +46,8 @@ struct KArgs {
   long long ws_peak_stride;
   // LDS carve-up (float offsets)
   int lds_region, lds_pcm, lds_logmel, lds_misc;
+  int lds_melpack, mel_pack_floats;  // float offset of the kernel-lifetime LDS copy of mel_pack, or -1
+  int lds_dct;  // float offset of the phase-B copy of dct_pack, or -1 to read it from global memory
 };
 
 constexpr int kKernelThreads = 512;

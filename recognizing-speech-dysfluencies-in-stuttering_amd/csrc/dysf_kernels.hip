@@ -46,46 +46,90 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// PCM tile staging: samples [s0, s0 + count) of the clip (zero outside [0, n)) -> LDS as float32.
-// int16 is loaded as aligned 32-bit pairs; the 1/32768 scale is exact.
-// Returns true if this thread saw a non-finite sample (float input only).
+// PCM tile staging in two halves so the HBM latency hides under the previous tile's FFT:
+//   pcm_prefetch  issues 16-byte coalesced loads of the samples [s0, s0 + count) of a clip into registers
+//   pcm_commit    converts (int16 * 2^-15 is exact) and writes them to the LDS tile as float32
+// The tile is stored from the 16-byte-aligned element a0 <= off + s0 onwards, so element (off + s) sits at
+// tile[(off + s) - a0] and every group lands on an aligned ds_write_b128; samples outside [0, n) are zero.
 template <int PCM>
-__device__ __forceinline__ bool stage_pcm(const void* pcm, long long off, long long n, long long s0, int count,
-                                          float* tile) {
-  bool bad = false;
-  if (PCM == DYSF_PCM_I16) {
-    const short* base = (const short*)pcm;
-    const long long a0 = (off + s0) & ~1LL;  // even element index (floor, also for negatives)
-    const int npairs = (int)(((off + s0 + count) - a0 + 1) >> 1);
-    for (int j = threadIdx.x; j < npairs; j += kThreads) {
-      const long long a = a0 + 2LL * j;
-      const bool v0 = (a >= off) && (a < off + n);
-      const bool v1 = (a + 1 >= off) && (a + 1 < off + n);
-      float f0 = 0.f, f1 = 0.f;
-      if (v0 && v1) {
-        const int w = *(const int*)(base + a);
-        f0 = (float)(short)(w & 0xffff) * (1.0f / 32768.0f);
-        f1 = (float)(w >> 16) * (1.0f / 32768.0f);
-      } else {
-        if (v0) f0 = (float)base[a] * (1.0f / 32768.0f);
-        if (v1) f1 = (float)base[a + 1] * (1.0f / 32768.0f);
-      }
-      const long long i0 = a - (off + s0);
-      if (i0 >= 0 && i0 < count) tile[i0] = f0;
-      if (i0 + 1 >= 0 && i0 + 1 < count) tile[i0 + 1] = f1;
-    }
-  } else {
-    const float* base = (const float*)pcm;
-    for (int j = threadIdx.x; j < count; j += kThreads) {
-      const long long s = s0 + j;
-      float f = 0.f;
-      if (s >= 0 && s < n) {
-        f = base[off + s];
-        bad |= !isfinite(f);
-      }
-      tile[j] = f;
+struct PcmStage {
+  static constexpr int EPG = (PCM == DYSF_PCM_I16) ? 8 : 4;            // elements per 16-byte group
+  static constexpr int MAXG = (PCM == DYSF_PCM_I16) ? 2 : 3;           // pipelined groups per thread; any tile
+  int4 g[MAXG];                                                        // beyond MAXG*512 groups is staged in place
+};
+
+template <int PCM>
+__device__ __forceinline__ long long pcm_tile_origin(long long off, long long s0) {
+  return (off + s0) & ~(long long)(PcmStage<PCM>::EPG - 1);  // floor, also for negative values
+}
+
+template <int PCM>
+__device__ __forceinline__ int4 pcm_load_group(const void* pcm, long long off, long long n, long long a) {
+  constexpr int EPG = PcmStage<PCM>::EPG;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (a >= off && a + EPG <= off + n) {
+    v = *(const int4*)((const char*)pcm + a * (PCM == DYSF_PCM_I16 ? 2 : 4));
+  } else if (a + EPG > off && a < off + n) {  // straddles a clip edge: element-wise, zero outside
+    if (PCM == DYSF_PCM_I16) {
+      const unsigned short* b = (const unsigned short*)pcm;
+      unsigned e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = (a + i >= off && a + i < off + n) ? (unsigned)b[a + i] : 0u;
+      v = make_int4((int)(e[0] | (e[1] << 16)), (int)(e[2] | (e[3] << 16)), (int)(e[4] | (e[5] << 16)),
+                    (int)(e[6] | (e[7] << 16)));
+    } else {
+      const int* b = (const int*)pcm;
+      int e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = (a + i >= off && a + i < off + n) ? b[a + i] : 0;
+      v = make_int4(e[0], e[1], e[2], e[3]);
     }
   }
+  return v;
+}
+
+// Returns true if a non-finite sample was seen (float input only).
+template <int PCM>
+__device__ __forceinline__ bool pcm_store_group(float* tile, int gi, int4 v) {
+  if (PCM == DYSF_PCM_I16) {
+    constexpr float sc = 1.0f / 32768.0f;
+    float4 lo, hi;
+    lo.x = (float)(short)(v.x & 0xffff) * sc; lo.y = (float)(v.x >> 16) * sc;
+    lo.z = (float)(short)(v.y & 0xffff) * sc; lo.w = (float)(v.y >> 16) * sc;
+    hi.x = (float)(short)(v.z & 0xffff) * sc; hi.y = (float)(v.z >> 16) * sc;
+    hi.z = (float)(short)(v.w & 0xffff) * sc; hi.w = (float)(v.w >> 16) * sc;
+    *(float4*)(tile + gi * 8) = lo;
+    *(float4*)(tile + gi * 8 + 4) = hi;
+    return false;
+  }
+  float4 f;
+  f.x = __int_as_float(v.x); f.y = __int_as_float(v.y); f.z = __int_as_float(v.z); f.w = __int_as_float(v.w);
+  *(float4*)(tile + gi * 4) = f;
+  return !(isfinite(f.x) && isfinite(f.y) && isfinite(f.z) && isfinite(f.w));
+}
+
+template <int PCM>
+__device__ __forceinline__ void pcm_prefetch(PcmStage<PCM>& st, const void* pcm, long long off, long long n,
+                                             long long a0, int ngroups) {
+#pragma unroll
+  for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
+    const int gi = threadIdx.x + j * kThreads;
+    st.g[j] = (gi < ngroups) ? pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG)
+                             : make_int4(0, 0, 0, 0);
+  }
+}
+
+template <int PCM>
+__device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile, const void* pcm, long long off,
+                                           long long n, long long a0, int ngroups) {
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
+    const int gi = threadIdx.x + j * kThreads;
+    if (gi < ngroups) bad |= pcm_store_group<PCM>(tile, gi, st.g[j]);
+  }
+  for (int gi = threadIdx.x + PcmStage<PCM>::MAXG * kThreads; gi < ngroups; gi += kThreads)  // oversized tiles
+    bad |= pcm_store_group<PCM>(tile, gi, pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG));
   return bad;
 }
 
@@ -284,6 +328,13 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * a.kpad;
 
+  // packed mel taps: copied once into LDS when there is room (the bench preset), else read through L2
+  const float* mel_src = a.mel_pack;
+  if (a.lds_melpack >= 0) {
+    float* ml = lds + a.lds_melpack;
+    for (int i = tid * 4; i < a.mel_pack_floats; i += kThreads * 4) *(float4*)(ml + i) = *(const float4*)(a.mel_pack + i);
+    mel_src = ml;
+  }
   const int C = a.n_mfcc;
   for (int clip = blockIdx.x; clip < a.n_clips; clip += gridDim.x) {
     const long long off = a.offsets[clip];
@@ -303,58 +354,93 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
     bool bad = false;
     const int ntiles = (st == DYSF_OK) ? (T + FPI - 1) / FPI : 0;
     const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+    constexpr int EPG = PcmStage<PCM>::EPG;
+    constexpr int CB = (FPI + 15) / 16;
     {
-    FftConsts<NC> fc;
-    load_fft_consts<NC>(fc, a, ls);
-    for (int ti = 0; ti < ntiles; ++ti) {
-      const int f0 = ti * FPI;
-      bad |= stage_pcm<PCM>(a.pcm, off, n, (long long)f0 * a.hop - NC, tile_samples, tile);
-      __syncthreads();
-      {
-        const int fl = wave * FPW + q;  // frame within tile
-        wave_frame_power<NC>(tile, fl * a.hop, xb, srow_own, ls, fc, a);
-        if (a.chroma)
-          frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[9], (int)a.ws_peak_stride);
+      FftConsts<NC> fc;
+      load_fft_consts<NC>(fc, a, ls);
+      PcmStage<PCM> stage;
+      auto tile_geom = [&](int ti, long long* a0, int* shift, int* ngroups) {
+        const long long s0 = (long long)ti * FPI * a.hop - NC;
+        *a0 = pcm_tile_origin<PCM>(off, s0);
+        *shift = (int)(off + s0 - *a0);
+        *ngroups = (int)((off + s0 + tile_samples - *a0 + EPG - 1) / EPG);
+      };
+      long long a0 = 0;
+      int shift = 0, ngroups = 0;
+      if (ntiles > 0) {
+        tile_geom(0, &a0, &shift, &ngroups);
+        pcm_prefetch<PCM>(stage, a.pcm, off, n, a0, ngroups);
+        bad |= pcm_commit<PCM>(stage, tile, a.pcm, off, n, a0, ngroups);
       }
       __syncthreads();
-      if (a.dbg_S) {
-        for (int i = tid; i < FPI * (NC + 1); i += kThreads) {
-          const int f = i / (NC + 1), k = i % (NC + 1);
-          if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
+      for (int ti = 0; ti < ntiles; ++ti) {
+        const int f0 = ti * FPI;
+        const int cur_shift = shift;
+        if (ti + 1 < ntiles) {  // loads for the next tile fly while this one is transformed
+          tile_geom(ti + 1, &a0, &shift, &ngroups);
+          pcm_prefetch<PCM>(stage, a.pcm, off, n, a0, ngroups);
         }
-      }
-      // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16]
-      constexpr int CB = (FPI + 15) / 16;
-      for (int t16 = wave; t16 < a.mel_rb * CB; t16 += kWaves) {
-        const int rb = t16 / CB, cb = t16 % CB;
-        const int kbeg = a.mel_meta[rb * 3], nst = a.mel_meta[rb * 3 + 1], poff = a.mel_meta[rb * 3 + 2];
-        int f = cb * 16 + (lane & 15);
-        const bool fvalid = f < FPI;
-        f = fvalid ? f : FPI - 1;
-        const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
-        const float* wp = a.mel_pack + poff + lane;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int kl = kbeg + (lane >> 4);
-        for (int s = 0; s < nst; ++s) {
-          const int k = kl + 4 * s;
-          const float bv = (k <= NC) ? srow[k] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s * 64], bv, acc, 0, 0, 0);
+        {
+          const int fl = wave * FPW + q;  // frame within tile
+          wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, fc, a);
+          if (a.chroma)
+            frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[9], (int)a.ws_peak_stride);
         }
-        const int t = f0 + f;
-        if (fvalid && t < T) {
+        __syncthreads();  // S tile complete; every wave is done reading the PCM tile
+        if (ti + 1 < ntiles) bad |= pcm_commit<PCM>(stage, tile, a.pcm, off, n, a0, ngroups);
+        if (a.dbg_S) {
+          for (int i = tid; i < FPI * (NC + 1); i += kThreads) {
+            const int f = i / (NC + 1), k = i % (NC + 1);
+            if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
+          }
+        }
+        // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16]
+        for (int t16 = wave; t16 < a.mel_rb * CB; t16 += kWaves) {
+          const int rb = t16 / CB, cb = t16 % CB;
+          const int kbeg = a.mel_meta[rb * 3], nst = a.mel_meta[rb * 3 + 1], poff = a.mel_meta[rb * 3 + 2];
+          int f = cb * 16 + (lane & 15);
+          const bool fvalid = f < FPI;
+          f = fvalid ? f : FPI - 1;
+          const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const int kl = kbeg + (lane >> 4);
+          const float* wp = mel_src + poff + lane;  // LDS copy when it fits, else L2-resident global pack
+          int s = 0;
+          for (; s + 8 <= nst; s += 8) {
+            float av[8], bv[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = rb * 16 + 4 * (lane >> 4) + r;
-            if (m < a.n_mels) {
-              const float v = 10.0f * log10f(fmaxf(a.amin, acc[r]));
-              lm[(size_t)t * a.mp + m] = v;
-              lmax = fmaxf(lmax, v);
+            for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int k = kl + 4 * (s + u);
+              bv[u] = (k <= NC) ? srow[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+          }
+          for (; s < nst; ++s) {
+            const int k = kl + 4 * s;
+            const float bv = (k <= NC) ? srow[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s * 64], bv, acc, 0, 0, 0);
+          }
+          const int t = f0 + f;
+          if (fvalid && t < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = rb * 16 + 4 * (lane >> 4) + r;
+              if (m < a.n_mels) {
+                // cells at the amin floor take the host-computed float32(10*log10(amin)) (-100 exactly for 1e-10):
+                // device log10f is a couple of ulp off there and every silent cell would repeat that error
+                const float v = (acc[r] <= a.amin) ? a.db_amin : 10.0f * log10f(acc[r]);
+                lm[(size_t)t * a.mp + m] = v;
+                lmax = fmaxf(lmax, v);
+              }
             }
           }
         }
+        __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
       }
-      // next iteration's staging barrier orders these S reads before the next FFT's LDS writes
-    }
     }
     if (PCM == DYSF_PCM_F32 && st == DYSF_OK) {
       // samples no frame touches (hop > n_fft/2 + 1) still invalidate the clip in librosa
@@ -396,6 +482,15 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s1[i][j] = 0.0; s2[i][j] = 0.0; kshift[i][j] = 0.f; }
     float* chunk = lds;  // aliases regions + PCM tile (phase A is over)
+    // float64 DCT A operands: staged into the LDS that phase A no longer needs (when they fit)
+    const double* dct_src = a.dct_pack;
+    __syncthreads();
+    if (a.lds_dct >= 0) {
+      double* dl = (double*)(lds + a.lds_dct);
+      const int nd = a.dct_rb * a.dct_steps * 64;
+      for (int i = tid * 2; i < nd; i += kThreads * 2) *(double2*)(dl + i) = *(const double2*)(a.dct_pack + i);
+      dct_src = dl;
+    }
     const int dct_tiles = a.dct_rb * (kChunkCols / 16);
     for (int t0 = 0; t0 < T; t0 += kChunk) {
       __syncthreads();
@@ -403,12 +498,23 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
         const int rb = t16 / (kChunkCols / 16), cb = t16 % (kChunkCols / 16);
         int t = t0 - 8 + cb * 16 + (lane & 15);
         t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-        const float* lrow = lm + (size_t)t * a.mp;
-        const double* dp = a.dct_pack + (size_t)rb * a.dct_steps * 64 + lane;
+        const float* lrow = lm + (size_t)t * a.mp + (lane >> 4);
+        const double* dp = dct_src + (size_t)rb * a.dct_steps * 64 + lane;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < a.dct_steps; ++s) {
-          const int m = 4 * s + (lane >> 4);
-          const double bv = (m < a.n_mels) ? (double)fmaxf(lrow[m], floor_db) : 0.0;
+        const int mrem = a.n_mels - (lane >> 4);  // this lane's B row is valid while 4*s < mrem
+        int s = 0;
+        for (; s + 4 <= a.dct_steps; s += 4) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = dp[(s + u) * 64];
+            bv[u] = (4 * (s + u) < mrem) ? (double)fmaxf(lrow[4 * (s + u)], floor_db) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        for (; s < a.dct_steps; ++s) {
+          const double bv = (4 * s < mrem) ? (double)fmaxf(lrow[4 * s], floor_db) : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dp[s * 64], bv, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -508,7 +614,6 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
       __syncthreads();
 
       // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the 8 waves)
-      constexpr int CB = (FPI + 15) / 16;
       float* part = misc + 128;             // [kWaves][CB][16 rows][16 cols]
       float* raw = part + kWaves * CB * 256;  // [16][CB*16]
       const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
@@ -518,9 +623,16 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
       load_fft_consts<NC>(fc, a, ls);
       for (int ti = 0; ti < ntiles; ++ti) {
         const int f0 = ti * FPI;
-        stage_pcm<PCM>(a.pcm, off, n, (long long)f0 * a.hop - NC, tile_samples, tile);
+        const long long cs0 = (long long)f0 * a.hop - NC;
+        const long long ca0 = pcm_tile_origin<PCM>(off, cs0);
+        {
+          PcmStage<PCM> stage;
+          const int cng = (int)((off + cs0 + tile_samples - ca0 + EPG - 1) / EPG);
+          pcm_prefetch<PCM>(stage, a.pcm, off, n, ca0, cng);
+          pcm_commit<PCM>(stage, tile, a.pcm, off, n, ca0, cng);
+        }
         __syncthreads();
-        wave_frame_power<NC>(tile, (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a);
+        wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a);
         __syncthreads();
         const int sb = (a.chroma_steps * wave) / kWaves, se = (a.chroma_steps * (wave + 1)) / kWaves;
         for (int cb = 0; cb < CB; ++cb) {
