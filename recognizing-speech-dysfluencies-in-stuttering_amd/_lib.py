@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdysf_hip.so")
+LIB_PATH = os.environ.get("DYSF_LIB") or os.path.join(_HERE, "libdysf_hip.so")  # DYSF_LIB: diagnostic builds
 
 DYSF_OK, DYSF_TOO_SHORT, DYSF_NONFINITE, DYSF_EMPTY = 0, 1, 2, 3
 STATUS_NAMES = {0: "OK", 1: "TOO_SHORT", 2: "NONFINITE", 3: "EMPTY"}

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,6 +45,9 @@ struct DysfHandle {
   HostTables t;
   int device = -1;
   int num_cu = 256;
+  int threads = 256;      // workgroup shape (DYSF_THREADS=256|512 overrides; see run_dev)
+  int force_logmel = 0;   // DYSF_LOGMEL=global forces the workspace variant
+  unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   size_t lds_limit = 163840;
   // device tables
   float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr, *d_mel_pack = nullptr,
@@ -90,6 +94,8 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   const char* err = "";
   if (!build_tables(*p, h->t, &err)) { delete h; return fail(DYSF_E_INVALID, err); }
   h->device = device;
+  if (const char* e = std::getenv("DYSF_THREADS")) { if (std::atoi(e) == 512) h->threads = 512; else if (std::atoi(e) == 256) h->threads = 256; }
+  if (const char* e = std::getenv("DYSF_LOGMEL")) { if (std::string(e) == "global") h->force_logmel = 1; }
   if (device >= 0) {
     int rc = 0;
     hipError_t e = hipSetDevice(device);
@@ -152,6 +158,18 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
   return n;
 }
 
+#ifdef DYSF_STAMP
+// diagnostic build only (not declared in dysf_hip.h): per-phase cycle sums of wave 0 [0..15] and the last wave [16..31]
+int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out32, int32_t reset) {
+  if (!h || h->device < 0) return DYSF_E_INVALID;
+  if (!h->dbg_stamps) { if (hipMalloc((void**)&h->dbg_stamps, 32 * 8) != hipSuccess) return DYSF_E_HIP; (void)hipMemset(h->dbg_stamps, 0, 32 * 8); }
+  (void)hipDeviceSynchronize();
+  if (out32) (void)hipMemcpy(out32, h->dbg_stamps, 32 * 8, hipMemcpyDeviceToHost);
+  if (reset) (void)hipMemset(h->dbg_stamps, 0, 32 * 8);
+  return 0;
+}
+#endif
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
@@ -177,6 +195,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.pcm = d_pcm; a.offsets = (const long long*)d_offsets; a.n_clips = n_clips;
   a.pooled = d_pooled; a.pooled_dim = dysf_pooled_dim(h); a.frames = d_frames; a.frame_stride = frame_stride;
   a.status = d_status; a.tuning = d_tuning; a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel;
+  a.dbg_stamps = h->dbg_stamps;
   a.sr = p.sr; a.hop = p.hop; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
   a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
   int mp = p.n_mels;
@@ -188,35 +207,49 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
 
-  // LDS carve-up (floats)
-  const int fpi = t.FPW * (kKernelThreads / 64);
+  // LDS carve-up (floats).  Two shapes: 256-thread workgroups with the clip's log-mel in a per-workgroup
+  // global workspace (small LDS footprint -> several workgroups per CU hide each other's barriers and LDS
+  // latency), or 512-thread workgroups that keep the log-mel in LDS (one workgroup per CU).
+  int threads = h->threads;
+  const int nw = threads / 64;
+  const int fpi = t.FPW * nw;
   int rstride = std::max(t.FPW * (t.NC + t.NC / 16), t.FPW * t.kpad);
   while (rstride % 32 != 8) ++rstride;
   a.rstride = rstride;
   const int tile_samples = ((fpi - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int cb = (fpi + 15) / 16;
-  const int misc = 128 + (p.chroma ? (kKernelThreads / 64) * cb * 256 + 16 * cb * 16 : 0);
+  const int misc = kMiscBaseFloats + (p.chroma ? nw * cb * 256 + 16 * cb * 16 : 0);
+  const int tables = (2 * t.NC + t.NC + 2 + 3) & ~3;
   a.lds_region = 0;
-  a.lds_pcm = (kKernelThreads / 64) * rstride;
+  a.lds_pcm = nw * rstride;
   a.lds_misc = a.lds_pcm + tile_samples;
-  a.lds_logmel = a.lds_misc + misc;
+  a.lds_tables = a.lds_misc + misc;
+  a.lds_logmel = a.lds_tables + tables;
   {  // phase B reuses [0, lds_misc): MFCC chunk first, then the float64 DCT operands if they fit
-    const int chunk_floats = ((t.cpad * 81 + 3) & ~3);
+    const int chunk_floats = ((t.cpad * (16 * nw + 1) + 3) & ~3);
     const int dct_floats = t.dct_pack.row_blocks * t.dct_pack.max_steps * 64 * 2;
+    if (chunk_floats > a.lds_misc) return fail(DYSF_E_INVALID, "internal: MFCC chunk does not fit the LDS scratch");
     a.lds_dct = (chunk_floats + dct_floats <= a.lds_misc) ? chunk_floats : -1;
   }
   const size_t fixed_bytes = (size_t)a.lds_logmel * 4;
   if (fixed_bytes > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
-  const bool lm_lds = fixed_bytes + (size_t)t_max * mp * 4 <= h->lds_limit;
+  bool lm_lds = (threads == 512) && fixed_bytes + (size_t)t_max * mp * 4 <= h->lds_limit;
+  if (h->force_logmel == 1) lm_lds = false;
   size_t lds_bytes = lm_lds ? fixed_bytes + (size_t)t_max * mp * 4 : fixed_bytes;
-  // the packed mel taps live in LDS for the whole kernel when there is room left
+  // the packed mel taps live in LDS for the whole kernel when that does not cost a resident workgroup
   a.mel_pack_floats = (int)t.mel_pack.data.size();
   a.lds_melpack = -1;
-  if (lds_bytes + (size_t)a.mel_pack_floats * 4 + 16 <= h->lds_limit) {
-    a.lds_melpack = (int)((lds_bytes / 4 + 3) & ~(size_t)3);
-    lds_bytes = ((size_t)a.lds_melpack + a.mel_pack_floats) * 4;
+  {
+    const size_t with_pack = (((lds_bytes / 4 + 3) & ~(size_t)3) + a.mel_pack_floats) * 4;
+    const size_t budget = lm_lds ? h->lds_limit : h->lds_limit / (threads == 256 ? 3 : 2);
+    if (with_pack <= budget) {
+      a.lds_melpack = (int)((lds_bytes / 4 + 3) & ~(size_t)3);
+      lds_bytes = with_pack;
+    }
   }
-  const int grid = std::min(n_clips, h->num_cu);
+  int wg_per_cu = 1;
+  if (!lm_lds) wg_per_cu = std::max<int>(1, std::min<int>(threads == 256 ? 3 : 1, (int)(h->lds_limit / lds_bytes)));
+  const int grid = std::min(n_clips, h->num_cu * wg_per_cu);
   if (!lm_lds) {
     if (int rc = h->ws_logmel.reserve((size_t)grid * t_max * mp * 4)) return rc;
     a.ws_logmel = (float*)h->ws_logmel.p;
@@ -230,7 +263,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.ws_peak_bin = (int*)h->ws_peak_bin.p;
     a.ws_peak_stride = cap;
   }
-  HIPCHK(launch_clip_kernel(a, p.n_fft, pcm_type, lm_lds, grid, lds_bytes, stream));
+  HIPCHK(launch_clip_kernel(a, p.n_fft, threads, pcm_type, lm_lds, grid, lds_bytes, stream));
   return 0;
 }
 

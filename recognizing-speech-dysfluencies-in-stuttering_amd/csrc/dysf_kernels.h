@@ -21,6 +21,7 @@ struct KArgs {
   int* tuning;
   float* dbg_S;       // [T][n_bins] of clip 0 (single-clip debug launches only)
   float* dbg_logmel;  // [T][n_mels]
+  unsigned long long* dbg_stamps;  // [32] cycle sums, DYSF_STAMP builds only
   // parameters
   int sr, hop, kpad, n_mels, mp, n_mfcc;
   float top_db, amin, db_amin;
@@ -45,14 +46,15 @@ struct KArgs {
   int* ws_peak_bin;
   long long ws_peak_stride;
   // LDS carve-up (float offsets)
-  int lds_region, lds_pcm, lds_logmel, lds_misc;
+  int lds_region, lds_pcm, lds_logmel, lds_misc, lds_tables;
   int lds_melpack, mel_pack_floats;  // float offset of the kernel-lifetime LDS copy of mel_pack, or -1
   int lds_dct;  // float offset of the phase-B copy of dct_pack, or -1 to read it from global memory
 };
 
-constexpr int kKernelThreads = 512;
+constexpr int kMiscBaseFloats = 864;  // fixed part of the misc LDS area (see dysf_kernels.hip)
 
-hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
-                              hipStream_t s);
+// threads: 256 (4 waves, several workgroups per CU, log-mel in the global workspace) or 512 (8 waves)
+hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int threads, int pcm_type, bool lm_lds, int grid,
+                              size_t lds_bytes, hipStream_t s);
 
 }  // namespace dysf

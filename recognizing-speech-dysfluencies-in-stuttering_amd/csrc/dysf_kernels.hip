@@ -21,11 +21,6 @@ namespace dysf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / 64;
-constexpr int kChunk = 64;       // output frames per phase-B chunk
-constexpr int kChunkCols = 80;   // DCT columns per chunk (64 + 8 halo each side)
-constexpr int kChunkStride = 81; // LDS row stride of the MFCC chunk
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in order; this only stops the compiler from reordering them.
@@ -55,7 +50,7 @@ template <int PCM>
 struct PcmStage {
   static constexpr int EPG = (PCM == DYSF_PCM_I16) ? 8 : 4;            // elements per 16-byte group
   static constexpr int MAXG = (PCM == DYSF_PCM_I16) ? 2 : 3;           // pipelined groups per thread; any tile
-  int4 g[MAXG];                                                        // beyond MAXG*512 groups is staged in place
+  int4 g[MAXG];                                                        // beyond MAXG*NT groups is staged in place
 };
 
 template <int PCM>
@@ -108,47 +103,43 @@ __device__ __forceinline__ bool pcm_store_group(float* tile, int gi, int4 v) {
   return !(isfinite(f.x) && isfinite(f.y) && isfinite(f.z) && isfinite(f.w));
 }
 
-template <int PCM>
+template <int PCM, int NT>
 __device__ __forceinline__ void pcm_prefetch(PcmStage<PCM>& st, const void* pcm, long long off, long long n,
                                              long long a0, int ngroups) {
 #pragma unroll
   for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
-    const int gi = threadIdx.x + j * kThreads;
+    const int gi = threadIdx.x + j * NT;
     st.g[j] = (gi < ngroups) ? pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG)
                              : make_int4(0, 0, 0, 0);
   }
 }
 
-template <int PCM>
+template <int PCM, int NT>
 __device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile, const void* pcm, long long off,
                                            long long n, long long a0, int ngroups) {
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
-    const int gi = threadIdx.x + j * kThreads;
+    const int gi = threadIdx.x + j * NT;
     if (gi < ngroups) bad |= pcm_store_group<PCM>(tile, gi, st.g[j]);
   }
-  for (int gi = threadIdx.x + PcmStage<PCM>::MAXG * kThreads; gi < ngroups; gi += kThreads)  // oversized tiles
+  for (int gi = threadIdx.x + PcmStage<PCM>::MAXG * NT; gi < ngroups; gi += NT)  // oversized tiles
     bad |= pcm_store_group<PCM>(tile, gi, pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG));
   return bad;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-lane constants of the wave FFT, loaded once per kernel.
+// Per-lane constants of the wave FFT: stage-1 twiddles stay in registers; the window and the
+// real-spectrum twiddles are read from small LDS tables (consecutive lanes -> consecutive words).
 template <int NC>
 struct FftConsts {
-  float win_e[kPts], win_o[kPts];  // window at samples 2n, 2n+1, n = ls + L*p
-  float t1r[kPts], t1i[kPts];      // stage-1 twiddles
+  float t1r[kPts], t1i[kPts];
 };
 
 template <int NC>
 __device__ __forceinline__ void load_fft_consts(FftConsts<NC>& c, const KArgs& a, int ls) {
-  constexpr int L = FftGeom<NC>::L;
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
-    const int n = ls + L * p;
-    c.win_e[p] = a.window[2 * n];
-    c.win_o[p] = a.window[2 * n + 1];
     c.t1r[p] = a.stage_tw[(ls * kPts + p) * 2];
     c.t1i[p] = a.stage_tw[(ls * kPts + p) * 2 + 1];
   }
@@ -175,7 +166,8 @@ __device__ __forceinline__ void fft_exchange(float* re, float* im, float* xb, in
 // xb and srow both live in the calling wave's private LDS region.
 template <int NC>
 __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_off, float* xb, float* srow,
-                                                 int ls, const FftConsts<NC>& c, const KArgs& a) {
+                                                 int ls, const FftConsts<NC>& c, const KArgs& a,
+                                                 const float* win /*LDS [2*NC]*/, const float* ptw /*LDS [NC/2+1][2]*/) {
   using G = FftGeom<NC>;
   constexpr int L = G::L;
   constexpr int LAST = G::NSTAGE - 1;
@@ -183,8 +175,8 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
     const int n = ls + L * p;
-    re[p] = tile[frame_off + 2 * n] * c.win_e[p];
-    im[p] = tile[frame_off + 2 * n + 1] * c.win_o[p];
+    re[p] = tile[frame_off + 2 * n] * win[2 * n];
+    im[p] = tile[frame_off + 2 * n + 1] * win[2 * n + 1];
   }
   fft_stage<NC, 0>(re, im, nullptr, nullptr);
   fft_exchange<NC, 0>(re, im, xb, ls);
@@ -225,7 +217,7 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int k = (i == 8) ? NC / 2 : ls + L * i;
-    const float wr = a.post_tw[2 * k], wi = a.post_tw[2 * k + 1];
+    const float wr = ptw[2 * k], wi = ptw[2 * k + 1];
     float pk, pm;
     rfft_pair_power(zkr[i], zki[i], zmr[i], zmi[i], wr, wi, &pk, &pm);
     if (i < 8 || ls == 0) {
@@ -290,6 +282,7 @@ __device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool fram
 }
 
 // r-th smallest (0-based) of the n positive floats in v, by bitwise binary search; all threads call.
+template <int NT>
 __device__ float block_select(const float* v, int n, int r, int* scratch) {
   unsigned prefix = 0u;
   for (int bit = 31; bit >= 0; --bit) {
@@ -297,7 +290,7 @@ __device__ float block_select(const float* v, int n, int r, int* scratch) {
     if (threadIdx.x == 0) *scratch = 0;
     __syncthreads();
     int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += kThreads) cnt += (__float_as_uint(v[i]) < cand) ? 1 : 0;
+    for (int i = threadIdx.x; i < n; i += NT) cnt += (__float_as_uint(v[i]) < cand) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(scratch, cnt);
     __syncthreads();
@@ -308,18 +301,44 @@ __device__ float block_select(const float* v, int n, int r, int* scratch) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NC, int PCM, bool LM_LDS>
-__global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
+// misc LDS area (float offsets)
+constexpr int kMiscWaveMax = 0;    // [16] per-wave running max of the log-mel
+constexpr int kMiscBad = 16;       // int: non-finite sample seen
+constexpr int kMiscPeakCnt = 17;   // int: peaks appended so far
+constexpr int kMiscScratch = 18;   // int: block_select counter
+constexpr int kMiscHist = 32;      // int[100]: tuning histogram
+constexpr int kMiscShift = 136;    // float[48][3]: frame-0 features (shift of the one-pass variance)
+constexpr int kMiscChroma = 864;   // chroma partial tiles
+
+#ifdef DYSF_STAMP
+// diagnostic build only: lane 0 of the first and last wave add the cycles since their previous stamp to slot i
+#define STAMP(i)                                                                                         \
+  do {                                                                                                   \
+    if (lane == 0 && (wave == 0 || wave == NW - 1) && a.dbg_stamps) {                                    \
+      const unsigned long long now_ = __builtin_readcyclecounter();                                      \
+      atomicAdd(&a.dbg_stamps[(wave == 0 ? 0 : 16) + (i)], now_ - stamp_last);                           \
+      stamp_last = now_;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+template <int NC, int PCM, bool LM_LDS, int NT>
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(const KArgs a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L, FPW = G::FPW;
-  constexpr int FPI = FPW * kWaves;  // frames per tile
+  constexpr int NW = NT / 64;
+  constexpr int FPI = FPW * NW;  // frames per tile
+  constexpr int CB = (FPI + 15) / 16;
+  constexpr int EPG = PcmStage<PCM>::EPG;
   extern __shared__ __align__(16) float lds[];
   float* regions = lds + a.lds_region;
   float* tile = lds + a.lds_pcm;
   float* lm_lds = lds + a.lds_logmel;
   float* misc = lds + a.lds_misc;
-  // misc layout (floats): [0..7] wave max, [8] bad flag (int), [9] peak count (int), [10] scratch (int),
-  // [16..115] histogram (int), [128..] chroma partial sums
+  float* win = lds + a.lds_tables;      // [2*NC] window
+  float* ptw = win + 2 * NC;            // [NC/2+1][2] real-spectrum twiddles
   int* imisc = (int*)misc;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,14 +347,19 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * a.kpad;
 
-  // packed mel taps: copied once into LDS when there is room (the bench preset), else read through L2
+  // kernel-lifetime LDS tables: window, un-packing twiddles, and (when there is room) the packed mel taps
+  for (int i = tid; i < 2 * NC; i += NT) win[i] = a.window[i];
+  for (int i = tid; i < NC + 2; i += NT) ptw[i] = a.post_tw[i];
   const float* mel_src = a.mel_pack;
   if (a.lds_melpack >= 0) {
     float* ml = lds + a.lds_melpack;
-    for (int i = tid * 4; i < a.mel_pack_floats; i += kThreads * 4) *(float4*)(ml + i) = *(const float4*)(a.mel_pack + i);
+    for (int i = tid * 4; i < a.mel_pack_floats; i += NT * 4) *(float4*)(ml + i) = *(const float4*)(a.mel_pack + i);
     mel_src = ml;
   }
   const int C = a.n_mfcc;
+#ifdef DYSF_STAMP
+  unsigned long long stamp_last = __builtin_readcyclecounter();
+#endif
   for (int clip = blockIdx.x; clip < a.n_clips; clip += gridDim.x) {
     const long long off = a.offsets[clip];
     const long long n = a.offsets[clip + 1] - off;
@@ -346,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
     float* lm = LM_LDS ? lm_lds : (a.ws_logmel + (size_t)blockIdx.x * a.ws_logmel_stride);
     float* pk_mag = a.ws_peak_mag ? a.ws_peak_mag + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
     int* pk_bin = a.ws_peak_bin ? a.ws_peak_bin + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
-    if (tid < 16) imisc[tid] = 0;
+    if (tid < 32) imisc[tid] = 0;
     __syncthreads();
 
     // ------------------------------------------------------------------ phase A
@@ -354,8 +378,6 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
     bool bad = false;
     const int ntiles = (st == DYSF_OK) ? (T + FPI - 1) / FPI : 0;
     const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
-    constexpr int EPG = PcmStage<PCM>::EPG;
-    constexpr int CB = (FPI + 15) / 16;
     {
       FftConsts<NC> fc;
       load_fft_consts<NC>(fc, a, ls);
@@ -370,33 +392,36 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
       int shift = 0, ngroups = 0;
       if (ntiles > 0) {
         tile_geom(0, &a0, &shift, &ngroups);
-        pcm_prefetch<PCM>(stage, a.pcm, off, n, a0, ngroups);
-        bad |= pcm_commit<PCM>(stage, tile, a.pcm, off, n, a0, ngroups);
+        pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
+        bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
       }
       __syncthreads();
+      STAMP(0);  // clip setup + first tile staged
       for (int ti = 0; ti < ntiles; ++ti) {
         const int f0 = ti * FPI;
         const int cur_shift = shift;
         if (ti + 1 < ntiles) {  // loads for the next tile fly while this one is transformed
           tile_geom(ti + 1, &a0, &shift, &ngroups);
-          pcm_prefetch<PCM>(stage, a.pcm, off, n, a0, ngroups);
+          pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
         }
         {
           const int fl = wave * FPW + q;  // frame within tile
-          wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, fc, a);
+          wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, fc, a, win, ptw);
           if (a.chroma)
-            frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[9], (int)a.ws_peak_stride);
+            frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[kMiscPeakCnt], (int)a.ws_peak_stride);
         }
+        STAMP(1);  // FFT
         __syncthreads();  // S tile complete; every wave is done reading the PCM tile
-        if (ti + 1 < ntiles) bad |= pcm_commit<PCM>(stage, tile, a.pcm, off, n, a0, ngroups);
+        STAMP(2);  // barrier wait
+        if (ti + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
         if (a.dbg_S) {
-          for (int i = tid; i < FPI * (NC + 1); i += kThreads) {
+          for (int i = tid; i < FPI * (NC + 1); i += NT) {
             const int f = i / (NC + 1), k = i % (NC + 1);
             if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
           }
         }
         // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16]
-        for (int t16 = wave; t16 < a.mel_rb * CB; t16 += kWaves) {
+        for (int t16 = wave; t16 < a.mel_rb * CB; t16 += NW) {
           const int rb = t16 / CB, cb = t16 % CB;
           const int kbeg = a.mel_meta[rb * 3], nst = a.mel_meta[rb * 3 + 1], poff = a.mel_meta[rb * 3 + 2];
           int f = cb * 16 + (lane & 15);
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
           const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const int kl = kbeg + (lane >> 4);
-          const float* wp = mel_src + poff + lane;  // LDS copy when it fits, else L2-resident global pack
+          const float* wp = mel_src + poff + lane;  // LDS copy when it fits, else the L2-resident global pack
           int s = 0;
           for (; s + 8 <= nst; s += 8) {
             float av[8], bv[8];
@@ -439,25 +464,27 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
             }
           }
         }
+        STAMP(3);  // commit + mel
         __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
+        STAMP(4);  // barrier wait
       }
     }
     if (PCM == DYSF_PCM_F32 && st == DYSF_OK) {
       // samples no frame touches (hop > n_fft/2 + 1) still invalidate the clip in librosa
-      for (long long s = tid; s < n; s += kThreads) bad |= !isfinite(((const float*)a.pcm)[off + s]);
-      if (bad) imisc[8] = 1;
+      for (long long s = tid; s < n; s += NT) bad |= !isfinite(((const float*)a.pcm)[off + s]);
+      if (bad) imisc[kMiscBad] = 1;
     }
     lmax = wave_max(lmax);
-    if (lane == 0) misc[wave] = lmax;
+    if (lane == 0) misc[kMiscWaveMax + wave] = lmax;
     __syncthreads();
-    if (PCM == DYSF_PCM_F32 && imisc[8]) st = DYSF_NONFINITE;
-    float clip_max = misc[0];
+    if (PCM == DYSF_PCM_F32 && imisc[kMiscBad]) st = DYSF_NONFINITE;
+    float clip_max = misc[kMiscWaveMax];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) clip_max = fmaxf(clip_max, misc[w]);
+    for (int w = 1; w < NW; ++w) clip_max = fmaxf(clip_max, misc[kMiscWaveMax + w]);
     const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
 
     if (a.dbg_logmel && st == DYSF_OK)
-      for (int i = tid; i < T * a.n_mels; i += kThreads)
+      for (int i = tid; i < T * a.n_mels; i += NT)
         a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.mp + (i % a.n_mels)];
 
     float* prow = a.pooled ? a.pooled + (size_t)clip * a.pooled_dim : nullptr;
@@ -465,119 +492,134 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
     if (tid == 0 && a.status) a.status[clip] = st;
 
     if (st != DYSF_OK) {  // the reference's "except -> zeros" row (pipeline1.py:237-239)
-      if (prow) for (int i = tid; i < a.pooled_dim; i += kThreads) prow[i] = 0.f;
-      if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += kThreads) frow[i] = 0.f;
+      if (prow) for (int i = tid; i < a.pooled_dim; i += NT) prow[i] = 0.f;
+      if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += NT) frow[i] = 0.f;
       if (tid == 0 && a.tuning) a.tuning[clip] = 50;
       __syncthreads();
       continue;
     }
 
     // ------------------------------------------------------------------ phase B
-    // rows owned by this wave: c = wave, wave + 8, ...; lane = frame within the chunk
-    constexpr int RPW = 6;  // ceil(48 / 8)
-    double s1[RPW][3], s2[RPW][3];
-    float kshift[RPW][3];
+    // Chunks of CH = 16*NW - 16 output frames.  Per chunk every wave runs the float64-MFMA DCT of one 16-frame
+    // column tile (8 halo frames each side of the chunk) against all row blocks, then owns the MFCC rows
+    // c = wave, wave + NW, ... for deltas, stores and statistics (a lane is a frame).  Mean / variance are
+    // one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane partials across
+    // the chunks, one float64 cross-lane reduction per clip.
+    constexpr int COLS = 16 * NW;
+    constexpr int CH = COLS - 16;
+    constexpr int CSTR = COLS + 1;          // LDS row stride of the MFCC chunk
+    constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
+    float* chunk = lds;                      // aliases regions + PCM tile (phase A is over)
+    float* kshift = misc + kMiscShift;
+    const double* dct_src = a.dct_pack;
+    __syncthreads();
+    if (a.lds_dct >= 0) {  // float64 DCT operands into the LDS phase A no longer needs (when they fit)
+      double* dl = (double*)(lds + a.lds_dct);
+      const int nd = a.dct_rb * a.dct_steps * 64;
+      for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dl + i) = *(const double2*)(a.dct_pack + i);
+      dct_src = dl;
+    }
+    float ps[RPW][6];
 #pragma unroll
     for (int i = 0; i < RPW; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { s1[i][j] = 0.0; s2[i][j] = 0.0; kshift[i][j] = 0.f; }
-    float* chunk = lds;  // aliases regions + PCM tile (phase A is over)
-    // float64 DCT A operands: staged into the LDS that phase A no longer needs (when they fit)
-    const double* dct_src = a.dct_pack;
-    __syncthreads();
-    if (a.lds_dct >= 0) {
-      double* dl = (double*)(lds + a.lds_dct);
-      const int nd = a.dct_rb * a.dct_steps * 64;
-      for (int i = tid * 2; i < nd; i += kThreads * 2) *(double2*)(dl + i) = *(const double2*)(a.dct_pack + i);
-      dct_src = dl;
-    }
-    const int dct_tiles = a.dct_rb * (kChunkCols / 16);
-    for (int t0 = 0; t0 < T; t0 += kChunk) {
+      for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
+    STAMP(5);  // max reduce, status, phase-B setup
+    for (int t0 = 0; t0 < T; t0 += CH) {
       __syncthreads();
-      for (int t16 = wave; t16 < dct_tiles; t16 += kWaves) {
-        const int rb = t16 / (kChunkCols / 16), cb = t16 % (kChunkCols / 16);
-        int t = t0 - 8 + cb * 16 + (lane & 15);
+      STAMP(6);  // barrier wait
+      {
+        int t = t0 - 8 + wave * 16 + (lane & 15);
         t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
         const float* lrow = lm + (size_t)t * a.mp + (lane >> 4);
-        const double* dp = dct_src + (size_t)rb * a.dct_steps * 64 + lane;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* dp = dct_src + lane;
         const int mrem = a.n_mels - (lane >> 4);  // this lane's B row is valid while 4*s < mrem
-        int s = 0;
-        for (; s + 4 <= a.dct_steps; s += 4) {
-          double av[4], bv[4];
+        f64x4 acc[3];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            av[u] = dp[(s + u) * 64];
+        for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < a.dct_steps; s += 4) {  // dct_steps is a multiple of 4 (n_mels padded to 16)
+          double bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
             bv[u] = (4 * (s + u) < mrem) ? (double)fmaxf(lrow[4 * (s + u)], floor_db) : 0.0;
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) {
+            if (rb < a.dct_rb) {
+              double av[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) av[u] = dp[((size_t)rb * a.dct_steps + s + u) * 64];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[rb], 0, 0, 0);
+            }
           }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-        }
-        for (; s < a.dct_steps; ++s) {
-          const double bv = (4 * s < mrem) ? (double)fmaxf(lrow[4 * s], floor_db) : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dp[s * 64], bv, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
-          chunk[(rb * 16 + (lane >> 4) + 4 * r) * kChunkStride + cb * 16 + (lane & 15)] = (float)acc[r];
+        for (int rb = 0; rb < 3; ++rb)
+          if (rb < a.dct_rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
+              chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
       }
+      STAMP(7);  // DCT
       __syncthreads();
-      const int t = t0 + lane;
-      const bool tv = t < T;
-      int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
-      tc = tv ? tc : 4;
-      const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
-      const int bc = tc - (t0 - 8);             // column of the delta centre
+      STAMP(8);  // barrier wait
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int c = wave + i * kWaves;
-        if (c < C) {
-          const float* row = chunk + c * kChunkStride;
-          const float x = row[bx];
-          float xc = 0.f, d = 0.f, dd = 0.f;
-          if (tv || t0 == 0) {
-            const int cc = (tv ? bc : 4 + 8);
-            xc = row[cc];
-            const float p1 = row[cc + 1], m1 = row[cc - 1], p2 = row[cc + 2], m2 = row[cc - 2];
-            const float p3 = row[cc + 3], m3 = row[cc - 3], p4 = row[cc + 4], m4 = row[cc - 4];
-            d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) / 60.f;
-            dd = (28.f * ((p4 - xc) + (m4 - xc)) + 7.f * ((p3 - xc) + (m3 - xc)) - 8.f * ((p2 - xc) + (m2 - xc)) -
-                  17.f * ((p1 - xc) + (m1 - xc))) / 462.f;
-          }
-          if (t0 == 0) {  // shift values = the features of frame 0 (lane 0 of the first chunk)
-            kshift[i][0] = __shfl(x, 0); kshift[i][1] = __shfl(d, 0); kshift[i][2] = __shfl(dd, 0);
-          }
-          if (tv) {
-            const double e0 = (double)x - (double)kshift[i][0];
-            const double e1 = (double)d - (double)kshift[i][1];
-            const double e2 = (double)dd - (double)kshift[i][2];
-            s1[i][0] += e0; s2[i][0] += e0 * e0;
-            s1[i][1] += e1; s2[i][1] += e1 * e1;
-            s1[i][2] += e2; s2[i][2] += e2 * e2;
-            if (frow) {
-              frow[(size_t)c * a.frame_stride + t] = x;
-              frow[(size_t)(C + c) * a.frame_stride + t] = d;
-              frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
+      for (int sub = 0; sub < (CH + 63) / 64; ++sub) {
+        const int t = t0 + sub * 64 + lane;
+        const bool tv = (sub * 64 + lane < CH) && (t < T);
+        int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
+        tc = tv ? tc : 4;
+        const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
+        const int bc = tc - (t0 - 8);             // column of the delta centre
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int c = wave + i * NW;
+          if (c < C) {
+            const float* row = chunk + c * CSTR;
+            const float x = row[bx];
+            float d = 0.f, dd = 0.f;
+            if (tv) {
+              const float xc = row[bc], x2 = xc + xc;
+              const float p1 = row[bc + 1], m1 = row[bc - 1], p2 = row[bc + 2], m2 = row[bc - 2];
+              const float p3 = row[bc + 3], m3 = row[bc - 3], p4 = row[bc + 4], m4 = row[bc - 4];
+              d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) * (1.0f / 60.0f);
+              dd = (28.f * ((p4 + m4) - x2) + 7.f * ((p3 + m3) - x2) - 8.f * ((p2 + m2) - x2) - 17.f * ((p1 + m1) - x2)) *
+                   (1.0f / 462.0f);
+            }
+            if (t0 == 0 && sub == 0) {  // shift values = the features of frame 0
+              if (lane == 0) { kshift[c * 3 + 0] = x; kshift[c * 3 + 1] = d; kshift[c * 3 + 2] = dd; }
+              wave_lds_sync();
+            }
+            if (tv) {
+              const float e0 = x - kshift[c * 3 + 0], e1 = d - kshift[c * 3 + 1], e2 = dd - kshift[c * 3 + 2];
+              ps[i][0] += e0; ps[i][1] += e1; ps[i][2] += e2;
+              ps[i][3] += e0 * e0; ps[i][4] += e1 * e1; ps[i][5] += e2 * e2;
+              if (frow) {
+                frow[(size_t)c * a.frame_stride + t] = x;
+                frow[(size_t)(C + c) * a.frame_stride + t] = d;
+                frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
+              }
             }
           }
         }
       }
     }
+    STAMP(9);  // last chunk's deltas, stats, stores
     if (frow && a.frame_stride > T) {  // zero-fill the padding columns
       const int padc = (int)(a.frame_stride - T);
-      for (int i = tid; i < 3 * C * padc; i += kThreads) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
+      for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
     }
     if (prow) {
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
-        const int c = wave + i * kWaves;
+        const int c = wave + i * NW;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const double m1 = wave_sum(s1[i][j]) / (double)T;
-          const double m2 = wave_sum(s2[i][j]) / (double)T;
+          const double m1 = wave_sum((double)ps[i][j]) / (double)T;
+          const double m2 = wave_sum((double)ps[i][3 + j]) / (double)T;
           if (c < C && lane == 0) {
             const double var = m2 - m1 * m1;
-            prow[j * 2 * C + c] = (float)((double)kshift[i][j] + m1);
+            prow[j * 2 * C + c] = (float)((double)kshift[c * 3 + j] + m1);
             prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
           }
         }
@@ -587,35 +629,35 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
 
     // ------------------------------------------------------------------ phase C: chroma
     if (a.chroma) {
-      int* hist = imisc + 16;
-      int npk = imisc[9];
+      int* hist = imisc + kMiscHist;
+      int npk = imisc[kMiscPeakCnt];
       npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
       int tune = 50;
       if (npk > 0) {
         float thr;
         if (npk & 1) {
-          thr = block_select(pk_mag, npk, npk / 2, &imisc[10]);
+          thr = block_select<NT>(pk_mag, npk, npk / 2, &imisc[kMiscScratch]);
         } else {
-          const float lo = block_select(pk_mag, npk, npk / 2 - 1, &imisc[10]);
-          const float hi = block_select(pk_mag, npk, npk / 2, &imisc[10]);
+          const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, &imisc[kMiscScratch]);
+          const float hi = block_select<NT>(pk_mag, npk, npk / 2, &imisc[kMiscScratch]);
           thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
         }
         if (tid < kTunings) hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < npk; i += kThreads)
+        for (int i = tid; i < npk; i += NT)
           if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
         __syncthreads();
-        int best = 0, bc = hist[0];
+        int best = 0, bcnt = hist[0];
         for (int i = 1; i < kTunings; ++i)
-          if (hist[i] > bc) { bc = hist[i]; best = i; }
+          if (hist[i] > bcnt) { bcnt = hist[i]; best = i; }
         tune = best;
       }
       if (tid == 0 && a.tuning) a.tuning[clip] = tune;
       __syncthreads();
 
-      // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the 8 waves)
-      float* part = misc + 128;             // [kWaves][CB][16 rows][16 cols]
-      float* raw = part + kWaves * CB * 256;  // [16][CB*16]
+      // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the waves)
+      float* part = misc + kMiscChroma;     // [NW][CB][16 rows][16 cols]
+      float* raw = part + NW * CB * 256;    // [16][CB*16]
       const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
       double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c
       float cshift = 0.f;
@@ -628,19 +670,32 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
         {
           PcmStage<PCM> stage;
           const int cng = (int)((off + cs0 + tile_samples - ca0 + EPG - 1) / EPG);
-          pcm_prefetch<PCM>(stage, a.pcm, off, n, ca0, cng);
-          pcm_commit<PCM>(stage, tile, a.pcm, off, n, ca0, cng);
+          pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, ca0, cng);
+          pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, ca0, cng);
         }
         __syncthreads();
-        wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a);
+        wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a, win, ptw);
         __syncthreads();
-        const int sb = (a.chroma_steps * wave) / kWaves, se = (a.chroma_steps * (wave + 1)) / kWaves;
+        const int sb = (a.chroma_steps * wave) / NW, se = (a.chroma_steps * (wave + 1)) / NW;
         for (int cb = 0; cb < CB; ++cb) {
           int f = cb * 16 + (lane & 15);
           f = f < FPI ? f : FPI - 1;
           const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          for (int s = sb; s < se; ++s) {
+          int s = sb;
+          for (; s + 8 <= se; s += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = bank[(s + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int k = 4 * (s + u) + (lane >> 4);
+              bv[u] = (k <= NC) ? srow[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+          }
+          for (; s < se; ++s) {
             const int k = 4 * s + (lane >> 4);
             const float bv = (k <= NC) ? srow[k] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bank[s * 64 + lane], bv, acc, 0, 0, 0);
@@ -650,11 +705,11 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
             part[((wave * CB + cb) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
         }
         __syncthreads();
-        for (int i = tid; i < CB * 256; i += kThreads) {
+        for (int i = tid; i < CB * 256; i += NT) {
           const int cb = i / 256, rc = i % 256;
           float v = 0.f;
 #pragma unroll
-          for (int w = 0; w < kWaves; ++w) v += part[(w * CB + cb) * 256 + rc];
+          for (int w = 0; w < NW; ++w) v += part[(w * CB + cb) * 256 + rc];
           raw[(rc / 16) * (CB * 16) + cb * 16 + (rc % 16)] = v;
         }
         __syncthreads();
@@ -689,15 +744,15 @@ __global__ __launch_bounds__(kThreads) void dysf_clip_kernel(const KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NC>
-static hipError_t launch_nc(const KArgs& a, int pcm_type, bool lm_lds, int grid, size_t lds_bytes, hipStream_t s) {
+template <int NC, int NT>
+static hipError_t launch_nt(const KArgs& a, int pcm_type, bool lm_lds, int grid, size_t lds_bytes, hipStream_t s) {
 #define DYSF_LAUNCH(PCMT, LM)                                                                             \
   do {                                                                                                    \
-    auto kern = dysf_clip_kernel<NC, PCMT, LM>;                                                           \
+    auto kern = dysf_clip_kernel<NC, PCMT, LM, NT>;                                                       \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                        (int)lds_bytes);                                                   \
     if (e != hipSuccess) return e;                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, s, a);                                \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, a);                                      \
     return hipGetLastError();                                                                             \
   } while (0)
   if (pcm_type == DYSF_PCM_I16) {
@@ -708,13 +763,21 @@ static hipError_t launch_nc(const KArgs& a, int pcm_type, bool lm_lds, int grid,
 #undef DYSF_LAUNCH
 }
 
-hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
-                              hipStream_t s) {
+template <int NC>
+static hipError_t launch_nc(const KArgs& a, int threads, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
+                            hipStream_t s) {
+  if (threads == 256) return launch_nt<NC, 256>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+  if (threads == 512) return launch_nt<NC, 512>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int threads, int pcm_type, bool lm_lds, int grid,
+                              size_t lds_bytes, hipStream_t s) {
   switch (n_fft) {
-    case 256: return launch_nc<128>(a, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 512: return launch_nc<256>(a, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 1024: return launch_nc<512>(a, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 2048: return launch_nc<1024>(a, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 256: return launch_nc<128>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 512: return launch_nc<256>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 1024: return launch_nc<512>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 2048: return launch_nc<1024>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
     default: return hipErrorInvalidValue;
   }
 }

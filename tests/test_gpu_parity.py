@@ -154,7 +154,8 @@ def test_all_zero_clip_matches_spec(ex149):
     assert f[0] == np.float32(-100.0 * np.sqrt(128.0))  # one float32 ulp is 1.2e-4 here: demand the exact rounding
     assert np.abs(f[1:]).max() <= 1e-6
     want = O.extract_audio_features(np.zeros(20000, np.float32), 16000)
-    assert np.abs(f - want).max() <= 1e-4
+    # the oracle's (scipy's) float32 DCT lands one ulp (1.2e-4) off the exact -100*sqrt(128); everything else is 0
+    assert abs(f[0] - want[0]) <= 1.3e-4 and np.abs(f[1:] - want[1:]).max() <= 1e-6
 
 
 def test_ragged_batch_equals_single_clip_calls(ex149, ex512):
