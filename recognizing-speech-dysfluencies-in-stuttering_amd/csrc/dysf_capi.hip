@@ -45,7 +45,7 @@ struct DysfHandle {
   HostTables t;
   int device = -1;
   int num_cu = 256;
-  int threads = 256;      // workgroup shape (DYSF_THREADS=256|512 overrides; see run_dev)
+  int threads = 512;      // workgroup shape (DYSF_THREADS=256|512 overrides; see run_dev)
   int force_logmel = 0;   // DYSF_LOGMEL=global forces the workspace variant
   unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   size_t lds_limit = 163840;

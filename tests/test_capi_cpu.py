@@ -1,0 +1,104 @@
+"""CPU tier: the C-ABI library loads without a GPU, exports every declared symbol, builds the same tables as
+the oracle, validates its arguments, and the host emulation of the wave FFT is exact."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rsd_amd
+from oracle import dysf_oracle as O
+from rsd_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "recognizing-speech-dysfluencies-in-stuttering_amd", "csrc")
+
+
+def test_library_exports_every_symbol_in_the_header():
+    hdr = open(os.path.join(ROOT, "include", "dysf_hip.h")).read()
+    declared = set(re.findall(r"\b(dysf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.dysf_abi_version() == 1
+
+
+def test_presets_mirror_reference_constants():
+    L = _lib.lib()
+    p = _lib.DysfParams()
+    assert L.dysf_params_preset(_lib.PRESET_REFERENCE_149, ctypes.byref(p)) == 0
+    assert (p.sr, p.n_fft, p.hop, p.n_mels, p.n_mfcc, p.chroma, p.delta_width) == (16000, 2048, 512, 128, 20, 1, 9)
+    assert L.dysf_params_preset(_lib.PRESET_BENCH_512, ctypes.byref(p)) == 0
+    assert (p.n_fft, p.hop, p.n_mels, p.n_mfcc, p.chroma) == (512, 160, 64, 40, 0)
+    assert L.dysf_params_preset(99, ctypes.byref(p)) < 0 and b"preset" in L.dysf_last_error()
+    assert rsd_amd.REFERENCE_149.total_feature_len == 149 and rsd_amd.REFERENCE_149.audio_feature_len == 144
+    assert rsd_amd.BENCH_512.audio_feature_len == 240
+
+
+@pytest.mark.parametrize("params,oparams", [(rsd_amd.REFERENCE_149, O.REFERENCE_149), (rsd_amd.BENCH_512, O.BENCH_512)],
+                         ids=["ref149", "bench512"])
+def test_host_tables_equal_oracle_tables(params, oparams):
+    ht = rsd_amd.HostTables(params)
+    mel = ht.table(1).reshape(params.n_mels, params.n_bins)
+    assert np.array_equal(mel, O.mel_filterbank(oparams))
+    dct = ht.table(2).reshape(params.n_mfcc, params.n_mels)
+    assert np.abs(dct - O.dct_matrix(params.n_mels, params.n_mfcc)).max() <= 6e-8
+    assert np.abs(ht.table(0) - O.hann_periodic(params.n_fft)).max() <= 6e-8
+    if params.chroma:
+        for ti in (0, 1, 37, 50, 63, 99):
+            bank = ht.table(3, ti).reshape(12, params.n_bins)
+            want = O.chroma_filterbank(oparams, O.tuning_grid()[ti])
+            assert np.abs(bank - want).max() <= 1e-7, ti
+    ht.close()
+
+
+def test_other_sample_rate_tables():
+    p = rsd_amd.FeatureParams(sr=22050)
+    ht = rsd_amd.HostTables(p)
+    assert np.array_equal(ht.table(1).reshape(128, 1025), O.mel_filterbank(O.FeatureParams(sr=22050)))
+    assert np.abs(ht.table(3, 12).reshape(12, 1025) - O.chroma_filterbank(O.FeatureParams(sr=22050), O.tuning_grid()[12])).max() <= 1e-7
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(n_fft=300), "n_fft"), (dict(hop=0), "hop"), (dict(n_mels=200), "n_mels"),
+                                    (dict(n_mfcc=64), "n_mfcc"), (dict(delta_width=5), "delta_width")])
+def test_create_rejects_unsupported_parameters(kw, msg):
+    with pytest.raises(_lib.DysfError) as e:
+        rsd_amd.HostTables(rsd_amd.FeatureParams(**kw))
+    assert msg in str(e.value)
+
+
+def test_deviceless_handle_refuses_compute_and_geometry_helpers_work():
+    L = _lib.lib()
+    ht = rsd_amd.HostTables(rsd_amd.BENCH_512)
+    assert L.dysf_pooled_dim(ht._h) == 240 and L.dysf_frame_rows(ht._h) == 120
+    assert L.dysf_num_frames(ht._h, 48000) == 301 and L.dysf_num_frames(ht._h, 0) == 1
+    pcm = np.zeros(16, np.int16)
+    off = np.array([0, 16], np.int64)
+    out = np.zeros(240, np.float32)
+    rc = L.dysf_extract_batch(ht._h, pcm.ctypes.data_as(ctypes.c_void_p), 0, off.ctypes.data_as(ctypes.c_void_p), 1,
+                              out.ctypes.data_as(ctypes.c_void_p), None, 0, None, None)
+    assert rc == -1 and b"device" in L.dysf_last_error()
+    assert L.dysf_extract_batch_dev(None, None, 0, None, 1, 0, None, None, 0, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly_not_silently():
+    code = ("import os, sys; os.environ['DYSF_LIB'] = '/nonexistent/libdysf_hip.so'; sys.path.insert(0, %r);\n"
+            "import numpy as np, rsd_amd\n"
+            "try:\n"
+            "    rsd_amd.extract_features(np.zeros(16000, np.float32), 16000)\n"
+            "except rsd_amd.DysfError as e:\n"
+            "    print('RAISED', 'no CPU fallback' in str(e))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_host_emulation_of_wave_fft():
+    exe = os.path.join(CSRC, "emu_fft_test")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", CSRC, "emu_fft_test"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout

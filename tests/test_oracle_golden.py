@@ -1,0 +1,101 @@
+"""CPU tier: the oracle against the reference's own known-answer data and against SciPy primitives."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.fft
+import scipy.signal
+
+from oracle import dysf_oracle as O
+
+
+def _pairs(golden_dir):
+    d = os.path.join(golden_dir, "ref_pairs")
+    for e in json.load(open(os.path.join(d, "index.json"))):
+        pcm, sr = O.read_wav_pcm16(os.path.join(d, e["id"] + ".wav"))
+        yield e, pcm, sr, np.load(os.path.join(d, e["id"] + ".npy"))
+
+
+def test_validation_record_of_all_888_reference_pairs(golden_dir):
+    rec = json.load(open(os.path.join(golden_dir, "validate_888.json")))
+    assert rec["n_pairs"] == 888 and rec["n_over_1e-4"] == 0
+    assert rec["max_abs_diff"] <= 1e-4
+    assert rec["block_max_abs_diff"]["chroma_stats"] <= 1e-6 and rec["block_max_abs_diff"]["text"] == 0.0
+
+
+def test_oracle_reproduces_committed_reference_vectors(golden_dir):
+    n = 0
+    for e, pcm, sr, gold in _pairs(golden_dir):
+        assert sr == 16000 and len(pcm) == e["n_samples"]
+        assert gold.dtype == np.float32 and gold.shape == (149,)
+        feats = O.extract_features(O.pcm16_to_float(pcm), sr)
+        assert feats.dtype == np.float32
+        assert np.abs(feats - gold).max() <= 1e-4, e
+        assert np.abs(feats[120:144] - gold[120:144]).max() <= 1e-6  # chroma incl. the tuning decision
+        assert (feats[144:] == 0).all() and (gold[144:] == 0).all()
+        n += 1
+    assert n == 13
+
+
+def test_config1_clip_is_among_the_fixtures(golden_dir):
+    idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
+    assert any(e["reference_stem"] == "F_0050_10y9m_1 (mp3cut.net)10" and e["n_samples"] == 53951 for e in idx)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_delta_equals_scipy_savgol_interp(order):
+    rng = np.random.default_rng(order)
+    x = (rng.standard_normal((20, 57)) * 40 - 100).astype(np.float32)
+    want = scipy.signal.savgol_filter(x, 9, deriv=order, polyorder=order, axis=-1, mode="interp")
+    got = O.delta(x, order)
+    assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-5
+    taps = O.delta_taps(order)
+    ref = np.arange(-4, 5) / 60.0 if order == 1 else np.array([28, 7, -8, -17, -20, -17, -8, 7, 28]) / 462.0
+    assert np.abs(taps - ref).max() < 1e-15
+    with pytest.raises(ValueError):
+        O.delta(x[:, :8], order)  # fewer than 9 frames: the reference turns this into a zeros row
+
+
+def test_dct_matrix_equals_scipy_ortho_dct():
+    rng = np.random.default_rng(0)
+    L = rng.standard_normal((128, 31))
+    want = scipy.fft.dct(L, axis=0, type=2, norm="ortho")[:20]
+    assert np.abs(O.dct_matrix(128, 20) @ L - want).max() < 1e-12
+
+
+def test_mel_bank_sparsity_matches_survey():
+    for p, nnz in ((O.BENCH_512, 498), (O.REFERENCE_149, 2020)):
+        W = O.mel_filterbank(p)
+        assert W.dtype == np.float32 and W.shape == (p.n_mels, p.n_bins)
+        assert int((W != 0).sum()) == nnz and (W >= 0).all() and (W.sum(axis=1) > 0).all()
+
+
+def test_tuning_grid_and_histogram_rule():
+    g = O.tuning_grid()
+    assert len(g) == 100 and g[0] == -0.5 and g[50] == 0.0
+    r = O.pitch_residuals(np.array([440.0, 27.5 * 2 ** (0.4999 / 12), 27.5 * 2 ** (0.5 / 12)], np.float32))
+    assert r.dtype == np.float32 and abs(r[0]) < 1e-6 and (r >= -0.5).all() and (r < 0.5).all()
+
+
+def test_error_convention_zero_rows():
+    ok = O.pcm16_to_float((np.sin(np.arange(9000) * 0.05) * 9000).astype(np.int16))
+    assert np.abs(O.extract_audio_features(ok, 16000)).max() > 0
+    assert (O.extract_audio_features(None, 16000) == 0).all()
+    assert (O.extract_audio_features(ok[:4000], 16000) == 0).all()        # 8 frames < 9
+    bad = ok.copy(); bad[7] = np.nan
+    assert (O.extract_audio_features(bad, 16000) == 0).all()
+    assert (O.extract_audio_features(np.zeros(0, np.float32), 16000) == 0).all()
+    f = O.extract_features(ok, 16000)
+    assert f.shape == (149,) and (f[144:] == 0).all()
+
+
+def test_all_zero_clip_spec():
+    f = O.extract_audio_features(np.zeros(20000, np.float32), 16000)
+    assert abs(f[0] + 100 * np.sqrt(128.0)) <= 2e-4 and np.abs(f[1:]).max() <= 1e-6
+
+
+def test_bench_preset_shapes():
+    y = O.pcm16_to_float((np.random.default_rng(1).standard_normal(48000) * 3000).astype(np.int16))
+    fr = O.frame_level_stack(y, O.BENCH_512)
+    assert fr.shape == (120, 301) and fr.dtype == np.float32 and np.isfinite(fr).all()
