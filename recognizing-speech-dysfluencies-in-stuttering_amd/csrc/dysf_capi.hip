@@ -104,7 +104,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->num_cu = v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
       h->lds_limit = (size_t)v;
-    rc |= upload(&h->d_window, h->t.window);
+    rc |= upload(&h->d_window, h->t.window_half);
     rc |= upload(&h->d_stage_tw, h->t.stage_tw);
     rc |= upload(&h->d_post_tw, h->t.post_tw);
     rc |= upload(&h->d_mel_pack, h->t.mel_pack.data);

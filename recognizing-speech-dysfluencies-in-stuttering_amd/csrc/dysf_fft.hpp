@@ -7,6 +7,10 @@
 // stages are Stockham autosort passes (radix 16 / 4 / 2 in registers) and the only data movement
 // between stages is a transpose through a wave-private LDS buffer.  Replaces the pocketfft rfft call
 // inside librosa.stft (reached from pipeline1.py:216 and :227).
+//
+// Complex values are two-float vectors so that on gfx950 every complex add is one v_pk_add_f32 (the
+// multiplications by -i fold into its op_sel / neg modifiers) and every complex multiply is one
+// v_pk_mul_f32 + one v_pk_fma_f32.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -20,6 +24,37 @@ namespace dysf {
 constexpr int kPts = 16;  // complex points per lane
 constexpr int kTunings = 100;  // histogram bins of librosa.pitch_tuning at resolution 0.01
 constexpr int kChroma = 12;
+
+#if defined(__clang__)
+typedef float cf __attribute__((ext_vector_type(2)));
+#define DYSF_SWAP(z) __builtin_shufflevector((z), (z), 1, 0)
+#else
+typedef float cf __attribute__((vector_size(8)));
+typedef int cf_mask_ __attribute__((vector_size(8)));
+#define DYSF_SWAP(z) __builtin_shuffle((z), (cf_mask_){1, 0})
+#endif
+
+DYSF_HD cf mk(float re, float im) { cf r = {re, im}; return r; }
+// z * (-i) = (im, -re)
+DYSF_HD cf mul_mi(cf z) { cf s = DYSF_SWAP(z); cf r = {s[0], -s[1]}; return r; }
+// z * (wr + i wi) with compile-time-constant twiddles: the (-wi, wi) vector is a literal
+DYSF_HD cf cmul_const(cf z, float wr, float wi) {
+  const cf a = {wr, wr}, b = {-wi, wi};
+  return z * a + DYSF_SWAP(z) * b;
+}
+// z * w with a run-time twiddle held in a register pair
+DYSF_HD cf cmul(cf z, cf w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(z), "v"(w));  // (zr*wr, zi*wr)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : "=v"(r) : "v"(z), "v"(w), "v"(t));                                     // (-zi*wi + t.lo, zr*wi + t.hi)
+  return r;
+#else
+  cf r = {z[0] * w[0] - z[1] * w[1], z[0] * w[1] + z[1] * w[0]};
+  return r;
+#endif
+}
 
 // LDS exchange-buffer padding: one float of padding every 16 keeps the stride-16 writes of the first
 // radix-16 pass on distinct banks.
@@ -41,81 +76,73 @@ struct FftGeom {
 
 // ---- small DFTs on register arrays, elements at stride ST -------------------------------------
 template <int ST>
-DYSF_HD void dft2(float* re, float* im) {
-  float ar = re[0], ai = im[0], br = re[ST], bi = im[ST];
-  re[0] = ar + br; im[0] = ai + bi;
-  re[ST] = ar - br; im[ST] = ai - bi;
+DYSF_HD void dft2(cf* z) {
+  const cf a = z[0], b = z[ST];
+  z[0] = a + b;
+  z[ST] = a - b;
 }
 
 // forward radix-4: X[u] = sum_q x[q] (-i)^(q u)
 template <int ST>
-DYSF_HD void dft4(float* re, float* im) {
-  float t0r = re[0] + re[2 * ST], t0i = im[0] + im[2 * ST];
-  float t1r = re[0] - re[2 * ST], t1i = im[0] - im[2 * ST];
-  float t2r = re[ST] + re[3 * ST], t2i = im[ST] + im[3 * ST];
-  float t3r = re[ST] - re[3 * ST], t3i = im[ST] - im[3 * ST];
-  re[0] = t0r + t2r;      im[0] = t0i + t2i;
-  re[ST] = t1r + t3i;     im[ST] = t1i - t3r;       // t1 - i t3
-  re[2 * ST] = t0r - t2r; im[2 * ST] = t0i - t2i;
-  re[3 * ST] = t1r - t3i; im[3 * ST] = t1i + t3r;   // t1 + i t3
-}
-
-DYSF_HD void cmul(float& r, float& i, float wr, float wi) {
-  float tr = r * wr - i * wi;
-  i = r * wi + i * wr;
-  r = tr;
+DYSF_HD void dft4(cf* z) {
+  const cf t0 = z[0] + z[2 * ST], t1 = z[0] - z[2 * ST];
+  const cf t2 = z[ST] + z[3 * ST], t3 = z[ST] - z[3 * ST];
+  const cf m = mul_mi(t3);
+  z[0] = t0 + t2;
+  z[ST] = t1 + m;       // t1 - i t3
+  z[2 * ST] = t0 - t2;
+  z[3 * ST] = t1 - m;   // t1 + i t3
 }
 
 // forward radix-16 on 16 contiguous registers, output in natural order.
 // n = q + 4p, k = s + 4u:  a[q][s] = sum_p x[q+4p] W4^(ps);  X[s+4u] = sum_q a[q][s] W16^(qs) W4^(qu).
-DYSF_HD void dft16(float* re, float* im) {
+DYSF_HD void dft16(cf* z) {
   constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
   constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
   constexpr float H = 0.70710678118654752440f;   // sqrt(1/2)
   // inner radix-4 over p for each q: elements q, q+4, q+8, q+12 (stride 4); result index s at q+4s
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dft4<4>(re + q, im + q);
+  for (int q = 0; q < 4; ++q) dft4<4>(z + q);
   // twiddles W16^(q s) on element q + 4s
-  cmul(re[1 + 4], im[1 + 4], C1, -S1);   // q1 s1: W^1
-  cmul(re[1 + 8], im[1 + 8], H, -H);     // q1 s2: W^2
-  cmul(re[1 + 12], im[1 + 12], S1, -C1); // q1 s3: W^3
-  cmul(re[2 + 4], im[2 + 4], H, -H);     // q2 s1: W^2
-  { float t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }  // q2 s2: W^4 = -i
-  cmul(re[2 + 12], im[2 + 12], -H, -H);  // q2 s3: W^6
-  cmul(re[3 + 4], im[3 + 4], S1, -C1);   // q3 s1: W^3
-  cmul(re[3 + 8], im[3 + 8], -H, -H);    // q3 s2: W^6
-  cmul(re[3 + 12], im[3 + 12], -C1, S1); // q3 s3: W^9
+  z[1 + 4] = cmul_const(z[1 + 4], C1, -S1);    // q1 s1: W^1
+  z[1 + 8] = cmul_const(z[1 + 8], H, -H);      // q1 s2: W^2
+  z[1 + 12] = cmul_const(z[1 + 12], S1, -C1);  // q1 s3: W^3
+  z[2 + 4] = cmul_const(z[2 + 4], H, -H);      // q2 s1: W^2
+  z[2 + 8] = mul_mi(z[2 + 8]);                 // q2 s2: W^4 = -i
+  z[2 + 12] = cmul_const(z[2 + 12], -H, -H);   // q2 s3: W^6
+  z[3 + 4] = cmul_const(z[3 + 4], S1, -C1);    // q3 s1: W^3
+  z[3 + 8] = cmul_const(z[3 + 8], -H, -H);     // q3 s2: W^6
+  z[3 + 12] = cmul_const(z[3 + 12], -C1, S1);  // q3 s3: W^9
   // outer radix-4 over q for each s: elements 4s + {0,1,2,3} (stride 1); result index u at 4s + u
 #pragma unroll
-  for (int s = 0; s < 4; ++s) dft4<1>(re + 4 * s, im + 4 * s);
+  for (int s = 0; s < 4; ++s) dft4<1>(z + 4 * s);
   // element 4s + u now holds X[s + 4u]; transpose the 4x4 register tile to natural order
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int u = s + 1; u < 4; ++u) {
-      float t = re[4 * s + u]; re[4 * s + u] = re[4 * u + s]; re[4 * u + s] = t;
-      t = im[4 * s + u]; im[4 * s + u] = im[4 * u + s]; im[4 * u + s] = t;
+      const cf t = z[4 * s + u]; z[4 * s + u] = z[4 * u + s]; z[4 * u + s] = t;
     }
 }
 
 // One Stockham stage on a lane's 16 points.  Point p = b + NB*r belongs to butterfly b (NB = 16/R
-// butterflies per lane), input slot r.  tw{r,i}[p] is the stage twiddle (ignored for stage 0).
+// butterflies per lane), input slot r.  tw[p] is the stage twiddle (ignored for stage 0).
 template <int NC, int S>
-DYSF_HD void fft_stage(float* re, float* im, const float* twr, const float* twi) {
+DYSF_HD void fft_stage(cf* z, const cf* tw) {
   constexpr int R = FftGeom<NC>::radix(S);
   constexpr int NB = kPts / R;
   if (S > 0) {
 #pragma unroll
-    for (int p = NB; p < kPts; ++p) cmul(re[p], im[p], twr[p], twi[p]);
+    for (int p = NB; p < kPts; ++p) z[p] = cmul(z[p], tw[p]);
   }
   if (R == 16) {
-    dft16(re, im);
+    dft16(z);
   } else if (R == 4) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) dft4<NB>(re + b, im + b);
+    for (int b = 0; b < NB; ++b) dft4<NB>(z + b);
   } else {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) dft2<NB>(re + b, im + b);
+    for (int b = 0; b < NB; ++b) dft2<NB>(z + b);
   }
 }
 
@@ -149,17 +176,18 @@ DYSF_HD void fft_twiddle_frac(int ls, int p, int* num, int* den) {
   *den = NS * R;
 }
 
-// Real-spectrum un-packing for the bin pair (k, NC-k): Zk = (a,b), Zm = Z[(NC-k)%NC] = (c,d),
-// W = exp(-2 pi i k / (2 NC)) = (wr, wi).  Returns |X[k]|^2 and |X[NC-k]|^2.
-DYSF_HD void rfft_pair_power(float a, float b, float c, float d, float wr, float wi, float* pk, float* pm) {
-  const float er = 0.5f * (a + c), ei = 0.5f * (b - d);
-  const float orr = 0.5f * (a - c), oi = 0.5f * (b + d);
-  const float tr = wr * oi + wi * orr;
-  const float ti = -(wr * orr - wi * oi);
-  const float xr = er + tr, xi = ei + ti;
-  const float yr = er - tr, yi = ei - ti;
-  *pk = xr * xr + xi * xi;
-  *pm = yr * yr + yi * yi;
+// Real-spectrum un-packing for the bin pair (k, NC-k).  The FFT input is pre-scaled by 1/2 (folded into the
+// window table), so with Zk = Z[k], Zm = Z[(NC-k)%NC] and V = -i exp(-2 pi i k / (2 NC)) = (wi, -wr):
+//   X[k] = (Zk + conj Zm) + V (Zk - conj Zm),   X[NC-k] = conj((Zk + conj Zm) - V (Zk - conj Zm)).
+// Returns |X[k]|^2 and |X[NC-k]|^2.
+DYSF_HD void rfft_pair_power(cf zk, cf zm, cf v, float* pk, float* pm) {
+  const cf cm = {zm[0], -zm[1]};
+  const cf e = zk + cm, o = zk - cm;
+  const cf t = cmul(o, v);
+  const cf x = e + t, y = e - t;
+  const cf x2 = x * x, y2 = y * y;
+  *pk = x2[0] + x2[1];
+  *pm = y2[0] + y2[1];
 }
 
 }  // namespace dysf

@@ -133,37 +133,33 @@ __device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile,
 // real-spectrum twiddles are read from small LDS tables (consecutive lanes -> consecutive words).
 template <int NC>
 struct FftConsts {
-  float t1r[kPts], t1i[kPts];
+  cf t1[kPts];
 };
 
 template <int NC>
 __device__ __forceinline__ void load_fft_consts(FftConsts<NC>& c, const KArgs& a, int ls) {
+  const cf* tw = (const cf*)a.stage_tw + ls * kPts;
 #pragma unroll
-  for (int p = 0; p < kPts; ++p) {
-    c.t1r[p] = a.stage_tw[(ls * kPts + p) * 2];
-    c.t1i[p] = a.stage_tw[(ls * kPts + p) * 2 + 1];
-  }
+  for (int p = 0; p < kPts; ++p) c.t1[p] = tw[p];
 }
 
 // Two-pass (re, then im) transpose of a lane's 16 points through the frame's exchange buffer.
 template <int NC, int SPREV>
-__device__ __forceinline__ void fft_exchange(float* re, float* im, float* xb, int ls) {
+__device__ __forceinline__ void fft_exchange(cf* z, float* xb, int ls) {
 #pragma unroll
-  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = re[p];
-  wave_lds_sync();
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-  for (int p = 0; p < kPts; ++p) re[p] = xb[pad_idx(fft_in_index<NC>(ls, p))];
-  wave_lds_sync();
+    for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = z[p][h];
+    wave_lds_sync();
 #pragma unroll
-  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = im[p];
-  wave_lds_sync();
-#pragma unroll
-  for (int p = 0; p < kPts; ++p) im[p] = xb[pad_idx(fft_in_index<NC>(ls, p))];
-  wave_lds_sync();
+    for (int p = 0; p < kPts; ++p) z[p][h] = xb[pad_idx(fft_in_index<NC>(ls, p))];
+    wave_lds_sync();
+  }
 }
 
 // Windowed frame (in the LDS PCM tile at float offset frame_off) -> power spectrum row srow[0..NC].
-// xb and srow both live in the calling wave's private LDS region.
+// xb and srow both live in the calling wave's private LDS region.  win holds the window pre-scaled by 1/2
+// (see rfft_pair_power), ptw the un-packing twiddles V[k].
 template <int NC>
 __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_off, float* xb, float* srow,
                                                  int ls, const FftConsts<NC>& c, const KArgs& a,
@@ -171,55 +167,44 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
   using G = FftGeom<NC>;
   constexpr int L = G::L;
   constexpr int LAST = G::NSTAGE - 1;
-  float re[kPts], im[kPts];
+  cf z[kPts];
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
     const int n = ls + L * p;
-    re[p] = tile[frame_off + 2 * n] * win[2 * n];
-    im[p] = tile[frame_off + 2 * n + 1] * win[2 * n + 1];
+    const cf x = {tile[frame_off + 2 * n], tile[frame_off + 2 * n + 1]};
+    z[p] = x * *(const cf*)(win + 2 * n);
   }
-  fft_stage<NC, 0>(re, im, nullptr, nullptr);
-  fft_exchange<NC, 0>(re, im, xb, ls);
-  fft_stage<NC, 1>(re, im, c.t1r, c.t1i);
+  fft_stage<NC, 0>(z, nullptr);
+  fft_exchange<NC, 0>(z, xb, ls);
+  fft_stage<NC, 1>(z, c.t1);
   if (G::NSTAGE == 3) {
-    fft_exchange<NC, 1>(re, im, xb, ls);
-    float t2r[kPts], t2i[kPts];
-    const float* tw2 = a.stage_tw + (size_t)L * kPts * 2;
+    fft_exchange<NC, 1>(z, xb, ls);
+    cf t2[kPts];
+    const cf* tw2 = (const cf*)a.stage_tw + (size_t)L * kPts + ls * kPts;
 #pragma unroll
-    for (int p = 0; p < kPts; ++p) {
-      t2r[p] = tw2[(ls * kPts + p) * 2];
-      t2i[p] = tw2[(ls * kPts + p) * 2 + 1];
-    }
-    fft_stage<NC, 2>(re, im, t2r, t2i);
+    for (int p = 0; p < kPts; ++p) t2[p] = tw2[p];
+    fft_stage<NC, 2>(z, t2);
   }
   // natural-order spectrum through the buffer; gather the (k, NC-k) pairs this lane un-packs
-  float zkr[9], zki[9], zmr[9], zmi[9];
+  cf zk[9], zm[9];
 #pragma unroll
-  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = re[p];
-  wave_lds_sync();
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int k = (i == 8) ? NC / 2 : ls + L * i;
-    zkr[i] = xb[pad_idx(k)];
-    zmr[i] = xb[pad_idx((NC - k) % NC)];
+    for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = z[p][h];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = (i == 8) ? NC / 2 : ls + L * i;
+      zk[i][h] = xb[pad_idx(k)];
+      zm[i][h] = xb[pad_idx((NC - k) % NC)];
+    }
+    wave_lds_sync();
   }
-  wave_lds_sync();
-#pragma unroll
-  for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = im[p];
-  wave_lds_sync();
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int k = (i == 8) ? NC / 2 : ls + L * i;
-    zki[i] = xb[pad_idx(k)];
-    zmi[i] = xb[pad_idx((NC - k) % NC)];
-  }
-  wave_lds_sync();
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int k = (i == 8) ? NC / 2 : ls + L * i;
-    const float wr = ptw[2 * k], wi = ptw[2 * k + 1];
     float pk, pm;
-    rfft_pair_power(zkr[i], zki[i], zmr[i], zmi[i], wr, wi, &pk, &pm);
+    rfft_pair_power(zk[i], zm[i], *(const cf*)(ptw + 2 * k), &pk, &pm);
     if (i < 8 || ls == 0) {
       srow[k] = pk;
       srow[NC - k] = pm;

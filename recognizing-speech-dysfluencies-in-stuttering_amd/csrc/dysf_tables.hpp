@@ -58,6 +58,7 @@ struct HostTables {
   int NC = 0, L = 0, FPW = 0, nstage = 0;
   int n_bins = 0, kpad = 0, mpad = 0, cpad = 0;
   std::vector<float> window;     // [n_fft]
+  std::vector<float> window_half;  // window / 2 (exact): what the kernel multiplies by
   std::vector<float> stage_tw;   // [(nstage-1)][L][16][2]
   std::vector<float> post_tw;    // [NC/2+1][2]
   std::vector<float> mel;        // [n_mels][n_bins]
@@ -114,8 +115,9 @@ inline void fill_fft_tables(HostTables& t) {
   t.post_tw.resize((NC / 2 + 1) * 2);
   for (int k = 0; k <= NC / 2; ++k) {
     const double a = -2.0 * M_PI * (double)k / (double)(2 * NC);
-    t.post_tw[2 * k] = (float)std::cos(a);
-    t.post_tw[2 * k + 1] = (float)std::sin(a);
+    // V[k] = -i exp(-2 pi i k / N) = (sin a, -cos a) with a = -2 pi k / N   (see rfft_pair_power)
+    t.post_tw[2 * k] = (float)std::sin(a);
+    t.post_tw[2 * k + 1] = (float)(-std::cos(a));
   }
 }
 
@@ -148,6 +150,8 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   // periodic Hann (scipy.signal.get_window('hann', n, fftbins=True))
   t.window.resize(n_fft);
   for (int n = 0; n < n_fft; ++n) t.window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)n_fft));
+  t.window_half.resize(n_fft);
+  for (int n = 0; n < n_fft; ++n) t.window_half[n] = 0.5f * t.window[n];
 
   // np.fft.rfftfreq(n_fft, 1/sr)
   const double val = 1.0 / ((double)n_fft * (1.0 / (double)sr));

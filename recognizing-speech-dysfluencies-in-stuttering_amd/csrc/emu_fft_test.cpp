@@ -11,31 +11,30 @@
 using namespace dysf;
 
 template <int NC, int S>
-static void run_stage(std::vector<float>& re, std::vector<float>& im) {
+static void run_stage(std::vector<cf>& z) {
   constexpr int L = FftGeom<NC>::L;
   std::vector<float> bufr(FftGeom<NC>::XSTRIDE + 64), bufi(FftGeom<NC>::XSTRIDE + 64);
   if (S > 0) {
     for (int ls = 0; ls < L; ++ls)
       for (int p = 0; p < kPts; ++p) {
-        bufr[pad_idx(fft_out_index<NC, (S > 0 ? S - 1 : 0)>(ls, p))] = re[ls * kPts + p];
-        bufi[pad_idx(fft_out_index<NC, (S > 0 ? S - 1 : 0)>(ls, p))] = im[ls * kPts + p];
+        bufr[pad_idx(fft_out_index<NC, (S > 0 ? S - 1 : 0)>(ls, p))] = z[ls * kPts + p][0];
+        bufi[pad_idx(fft_out_index<NC, (S > 0 ? S - 1 : 0)>(ls, p))] = z[ls * kPts + p][1];
       }
     for (int ls = 0; ls < L; ++ls)
       for (int p = 0; p < kPts; ++p) {
-        re[ls * kPts + p] = bufr[pad_idx(fft_in_index<NC>(ls, p))];
-        im[ls * kPts + p] = bufi[pad_idx(fft_in_index<NC>(ls, p))];
+        z[ls * kPts + p][0] = bufr[pad_idx(fft_in_index<NC>(ls, p))];
+        z[ls * kPts + p][1] = bufi[pad_idx(fft_in_index<NC>(ls, p))];
       }
   }
   for (int ls = 0; ls < L; ++ls) {
-    float twr[kPts], twi[kPts];
+    cf tw[kPts];
     for (int p = 0; p < kPts; ++p) {
       int num, den;
       fft_twiddle_frac<NC, S>(ls, p, &num, &den);
       double a = -2.0 * M_PI * (double)num / (double)den;
-      twr[p] = (float)std::cos(a);
-      twi[p] = (float)std::sin(a);
+      tw[p] = mk((float)std::cos(a), (float)std::sin(a));
     }
-    fft_stage<NC, S>(&re[ls * kPts], &im[ls * kPts], twr, twi);
+    fft_stage<NC, S>(&z[ls * kPts], tw);
   }
 }
 
@@ -47,23 +46,22 @@ static double test_one(unsigned seed) {
   std::vector<double> x(N);
   srand(seed);
   for (int n = 0; n < N; ++n) x[n] = (rand() / (double)RAND_MAX - 0.5) * 2.0;
-  std::vector<float> re(L * kPts), im(L * kPts);
+  std::vector<cf> z(L * kPts);
   for (int ls = 0; ls < L; ++ls)
     for (int p = 0; p < kPts; ++p) {
       int n = fft_in_index<NC>(ls, p);
-      re[ls * kPts + p] = (float)x[2 * n];
-      im[ls * kPts + p] = (float)x[2 * n + 1];
+      z[ls * kPts + p] = mk(0.5f * (float)x[2 * n], 0.5f * (float)x[2 * n + 1]);  // the kernel's window carries the 1/2
     }
-  run_stage<NC, 0>(re, im);
-  run_stage<NC, 1>(re, im);
-  if (NS == 3) run_stage<NC, 2>(re, im);
+  run_stage<NC, 0>(z);
+  run_stage<NC, 1>(z);
+  if (NS == 3) run_stage<NC, 2>(z);
   // final store, natural order
   std::vector<float> zr(FftGeom<NC>::XSTRIDE + 64), zi(FftGeom<NC>::XSTRIDE + 64);
   for (int ls = 0; ls < L; ++ls)
     for (int p = 0; p < kPts; ++p) {
       int o = (NS == 3) ? fft_out_index<NC, 2>(ls, p) : fft_out_index<NC, 1>(ls, p);
-      zr[pad_idx(o)] = re[ls * kPts + p];
-      zi[pad_idx(o)] = im[ls * kPts + p];
+      zr[pad_idx(o)] = z[ls * kPts + p][0];
+      zi[pad_idx(o)] = z[ls * kPts + p][1];
     }
   std::vector<float> S(NC + 1, -1.f);
   for (int ls = 0; ls < L; ++ls)
@@ -73,8 +71,8 @@ static double test_one(unsigned seed) {
       int m = (NC - k) % NC;
       double a = -2.0 * M_PI * k / (double)N;
       float pk, pm;
-      rfft_pair_power(zr[pad_idx(k)], zi[pad_idx(k)], zr[pad_idx(m)], zi[pad_idx(m)], (float)std::cos(a),
-                      (float)std::sin(a), &pk, &pm);
+      rfft_pair_power(mk(zr[pad_idx(k)], zi[pad_idx(k)]), mk(zr[pad_idx(m)], zi[pad_idx(m)]),
+                      mk((float)std::sin(a), (float)(-std::cos(a))), &pk, &pm);
       S[k] = pk;
       S[NC - k] = pm;
     }
