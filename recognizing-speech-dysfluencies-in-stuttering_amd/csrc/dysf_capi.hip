@@ -57,6 +57,8 @@ struct DysfHandle {
   // workspace / staging
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin;
   DevBuf st_pcm, st_off, st_pooled, st_frames, st_status, st_tuning;
+  DevBuf d_mel_sched;
+  int sched_threads = 0, mel_slots = 0;
 };
 
 template <typename T>
@@ -126,7 +128,7 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_chroma_pack);
     h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
-    h->st_status.release(); h->st_tuning.release();
+    h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release();
   }
   delete h;
 }
@@ -171,6 +173,55 @@ int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out32, int32_t reset) {
 #endif
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Mel schedule: every (column block, row block) band is a run of K-steps; runs are dealt to the waves in order with
+// a per-wave budget of ceil(total / waves), splitting a band across waves where needed (partial sums meet in LDS).
+static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::vector<int32_t>& sched, int* nslots) {
+  const int stride = kMelSchedStride;
+  sched.assign((size_t)nw * stride, 0);
+  const MfmaPack& mp = t.mel_pack;
+  struct Part { int w, idx; };
+  int slots = 0;
+  const bool per_cb = (cb_count > 0) && (nw % cb_count == 0);
+  const int groups = per_cb ? cb_count : 1;
+  const int wpg = nw / groups;
+  for (int g = 0; g < groups; ++g) {
+    int total = 0;
+    for (int cb = (per_cb ? g : 0); cb < (per_cb ? g + 1 : cb_count); ++cb)
+      for (int rb = 0; rb < mp.row_blocks; ++rb) total += mp.meta[rb * 3 + 1];
+    const int target = (total + wpg - 1) / wpg;
+    int w = g * wpg, wend = (g + 1) * wpg - 1, cap = target;
+    for (int cb = (per_cb ? g : 0); cb < (per_cb ? g + 1 : cb_count); ++cb)
+      for (int rb = 0; rb < mp.row_blocks; ++rb) {
+        const int kbeg = mp.meta[rb * 3], nst = mp.meta[rb * 3 + 1], poff = mp.meta[rb * 3 + 2];
+        int s0 = 0, rem = nst;
+        std::vector<Part> parts;
+        while (rem > 0) {
+          int& nseg = sched[(size_t)w * stride + kMelMaxSeg * 8];
+          if (w < wend && (cap < std::min(rem, 4) || nseg >= kMelMaxSeg)) { ++w; cap = target; continue; }
+          int take = (w == wend) ? rem : std::min(rem, cap);
+          if (w < wend && rem - take > 0 && rem - take < 4) take = rem;  // no slivers
+          int* q = &sched[(size_t)w * stride + (size_t)std::min(nseg, kMelMaxSeg - 1) * 8];
+          q[0] = rb; q[1] = cb; q[2] = kbeg + 4 * s0; q[3] = take; q[4] = poff + s0 * 64; q[5] = 0; q[6] = 0; q[7] = 0;
+          parts.push_back({w, std::min(nseg, kMelMaxSeg - 1)});
+          if (nseg < kMelMaxSeg) ++nseg;
+          s0 += take; rem -= take; cap -= take;
+          if (cap <= 0 && w < wend) { ++w; cap = target; }
+        }
+        if (parts.size() > 1) {
+          const int first_slot = slots;
+          for (size_t i = 0; i + 1 < parts.size(); ++i) {
+            int* q = &sched[(size_t)parts[i].w * stride + (size_t)parts[i].idx * 8];
+            q[5] = 1; q[6] = slots++;
+          }
+          int* q = &sched[(size_t)parts.back().w * stride + (size_t)parts.back().idx * 8];
+          q[5] = 2; q[6] = first_slot; q[7] = (int)parts.size() - 1;
+        }
+      }
+  }
+  *nslots = slots;
+}
 
 // ------------------------------------------------------------------------------------------------
 static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t* d_offsets, int n_clips,
@@ -218,7 +269,16 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.rstride = rstride;
   const int tile_samples = ((fpi - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int cb = (fpi + 15) / 16;
-  const int misc = kMiscBaseFloats + (p.chroma ? nw * cb * 256 + 16 * cb * 16 : 0);
+  if (h->sched_threads != threads) {
+    std::vector<int32_t> sched;
+    build_mel_schedule(t, nw, cb, sched, &h->mel_slots);
+    if (int rc = h->d_mel_sched.reserve(sched.size() * 4)) return rc;
+    HIPCHK(hipMemcpy(h->d_mel_sched.p, sched.data(), sched.size() * 4, hipMemcpyHostToDevice));
+    h->sched_threads = threads;
+  }
+  a.mel_sched = (const int*)h->d_mel_sched.p;
+  a.mel_slots = h->mel_slots;
+  const int misc = kMiscBaseFloats + h->mel_slots * 256 + (p.chroma ? nw * cb * 256 + 16 * cb * 16 : 0);
   const int tables = (2 * t.NC + t.NC + 2 + 3) & ~3;
   a.lds_region = 0;
   a.lds_pcm = nw * rstride;
@@ -263,6 +323,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.ws_peak_bin = (int*)h->ws_peak_bin.p;
     a.ws_peak_stride = cap;
   }
+  if (std::getenv("DYSF_VERBOSE"))
+    std::fprintf(stderr, "[dysf] threads %d grid %d lds %zu B (limit %zu) logmel %s melpack %s dct %s slots %d tile %d floats\n", threads, grid, lds_bytes, h->lds_limit, lm_lds ? "lds" : "global", a.lds_melpack >= 0 ? "lds" : "global", a.lds_dct >= 0 ? "lds" : "global", a.mel_slots, tile_samples);
   HIPCHK(launch_clip_kernel(a, p.n_fft, threads, pcm_type, lm_lds, grid, lds_bytes, stream));
   return 0;
 }

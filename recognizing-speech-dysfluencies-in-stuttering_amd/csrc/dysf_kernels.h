@@ -34,6 +34,8 @@ struct KArgs {
   const float* mel_pack;
   const int* mel_meta;
   int mel_rb, mel_max_steps;
+  const int* mel_sched;  // per wave kMelSchedStride ints (see below)
+  int mel_slots;         // split-K partial tiles kept in LDS
   const double* dct_pack;  // float64 A operands
   int dct_rb, dct_steps;
   const float* chroma_pack;
@@ -51,7 +53,9 @@ struct KArgs {
   int lds_dct;  // float offset of the phase-B copy of dct_pack, or -1 to read it from global memory
 };
 
-constexpr int kMiscBaseFloats = 864;  // fixed part of the misc LDS area (see dysf_kernels.hip)
+constexpr int kMelMaxSeg = 4;
+constexpr int kMelSchedStride = 40;  // ints per wave: kMelMaxSeg x {rb, cb, kbeg, nsteps, poff, kind, slot, nparts}, nseg at [32]
+constexpr int kMiscBaseFloats = 288 + 8 * kMelSchedStride;  // fixed part of the misc LDS area (see dysf_kernels.hip)
 
 // threads: 256 (4 waves, several workgroups per CU, log-mel in the global workspace) or 512 (8 waves)
 hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int threads, int pcm_type, bool lm_lds, int grid,

@@ -286,14 +286,69 @@ __device__ float block_select(const float* v, int n, int r, int* scratch) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One segment of the mel schedule: K-steps [kbeg, kbeg + 4*nsteps) of row block rb against column block cb.
+struct MelSeg { int rb, cb, kbeg, nsteps, poff, kind, slot, nparts; };  // kind 0 whole, 1 partial writer, 2 finisher
+
+template <int NC, int FPW, int FPI>
+__device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& a, const float* mel_src,
+                                             const MelSeg& g, int lane) {
+  int f = g.cb * 16 + (lane & 15);
+  f = f < FPI ? f : FPI - 1;
+  const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad + g.kbeg + (lane >> 4);
+  const float* wp = mel_src + g.poff + lane;  // LDS copy when it fits, else the L2-resident global pack
+  const int krem = NC - g.kbeg - (lane >> 4);  // B row valid while 4*s <= krem
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA latency
+  // batches of 8 K-steps: 16 LDS reads in flight, then 8 MFMAs; steps past the end of the segment multiply by a
+  // zero tap (the pack is padded so the speculative tap reads stay inside it)
+  for (int s = 0; s < g.nsteps; s += 8) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bv[u] = (4 * (s + u) <= krem) ? srow[4 * (s + u)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = (s + u < g.nsteps) ? av[u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
+    }
+  }
+  return acc0 + acc1;
+}
+
+// 10*log10 of a finished mel tile -> log-mel rows, running max
+template <int FPI>
+__device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const KArgs& a, float* lm, int f0, int T,
+                                             int lane, float& lmax) {
+  const int f = g.cb * 16 + (lane & 15);
+  const int t = f0 + f;
+  if (f < FPI && t < T) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = g.rb * 16 + 4 * (lane >> 4) + r;
+      if (m < a.n_mels) {
+        // 10*log10(x) = log2(x) * 10*log10(2), v_log_f32 plus a two-term constant.  Cells at the amin floor take
+        // the host-computed float32(10*log10(amin)) (-100 exactly for 1e-10) so that silent cells are exact.
+        const float l2 = __builtin_amdgcn_logf(acc[r]);
+        const float v = (acc[r] <= a.amin) ? a.db_amin : fmaf(l2, 3.0102999566398120f - 3.01029992103576660f, l2 * 3.01029992103576660f);
+        lm[(size_t)t * a.mp + m] = v;
+        lmax = fmaxf(lmax, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // misc LDS area (float offsets)
 constexpr int kMiscWaveMax = 0;    // [16] per-wave running max of the log-mel
 constexpr int kMiscBad = 16;       // int: non-finite sample seen
 constexpr int kMiscPeakCnt = 17;   // int: peaks appended so far
 constexpr int kMiscScratch = 18;   // int: block_select counter
-constexpr int kMiscHist = 32;      // int[100]: tuning histogram
-constexpr int kMiscShift = 136;    // float[48][3]: frame-0 features (shift of the one-pass variance)
-constexpr int kMiscChroma = 864;   // chroma partial tiles
+constexpr int kMiscShift = 32;     // float[48][3]: frame-0 features (shift of the one-pass variance)
+constexpr int kMiscHist = 176;     // int[100]: tuning histogram
+constexpr int kMiscSched = 288;    // int[NW][kMelSchedStride] mel schedule (NW <= 8)
+constexpr int kMiscSlots = 288 + 8 * kMelSchedStride;    // mel split-K partial tiles: nslots x 64 lanes x 4 floats; chroma partials follow
 
 #ifdef DYSF_STAMP
 // diagnostic build only: lane 0 of the first and last wave add the cycles since their previous stamp to slot i
@@ -341,6 +396,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(cons
     for (int i = tid * 4; i < a.mel_pack_floats; i += NT * 4) *(float4*)(ml + i) = *(const float4*)(a.mel_pack + i);
     mel_src = ml;
   }
+  // the mel schedule (host-built, per wave: kMelMaxSeg x 8 ints, then nseg) is copied to LDS once
+  int* sched = (int*)(misc + kMiscSched);
+  for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
+  const int* wsched = sched + wave * kMelSchedStride;
+  float* slots = misc + kMiscSlots;
+  f32x4 pend = {0.f, 0.f, 0.f, 0.f};
   const int C = a.n_mfcc;
 #ifdef DYSF_STAMP
   unsigned long long stamp_last = __builtin_readcyclecounter();
@@ -405,53 +466,34 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(cons
             if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
           }
         }
-        // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16]
-        for (int t16 = wave; t16 < a.mel_rb * CB; t16 += NW) {
-          const int rb = t16 / CB, cb = t16 % CB;
-          const int kbeg = a.mel_meta[rb * 3], nst = a.mel_meta[rb * 3 + 1], poff = a.mel_meta[rb * 3 + 2];
-          int f = cb * 16 + (lane & 15);
-          const bool fvalid = f < FPI;
-          f = fvalid ? f : FPI - 1;
-          const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          const int kl = kbeg + (lane >> 4);
-          const float* wp = mel_src + poff + lane;  // LDS copy when it fits, else the L2-resident global pack
-          int s = 0;
-          for (; s + 8 <= nst; s += 8) {
-            float av[8], bv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int k = kl + 4 * (s + u);
-              bv[u] = (k <= NC) ? srow[k] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16], following this wave's
+        // slice of the host-built schedule (row blocks with long bands are split along K over several waves)
+        MelSeg fin;
+        fin.kind = 0;
+        const int nseg = wsched[kMelMaxSeg * 8];
+        for (int i = 0; i < nseg; ++i) {
+          MelSeg g;
+          {
+            const int4 lo = *(const int4*)(wsched + i * 8), hi = *(const int4*)(wsched + 4 + i * 8);
+            g.rb = lo.x; g.cb = lo.y; g.kbeg = lo.z; g.nsteps = lo.w; g.poff = hi.x; g.kind = hi.y; g.slot = hi.z; g.nparts = hi.w;
           }
-          for (; s < nst; ++s) {
-            const int k = kl + 4 * s;
-            const float bv = (k <= NC) ? srow[k] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s * 64], bv, acc, 0, 0, 0);
-          }
-          const int t = f0 + f;
-          if (fvalid && t < T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = rb * 16 + 4 * (lane >> 4) + r;
-              if (m < a.n_mels) {
-                // cells at the amin floor take the host-computed float32(10*log10(amin)) (-100 exactly for 1e-10):
-                // device log10f is a couple of ulp off there and every silent cell would repeat that error
-                const float v = (acc[r] <= a.amin) ? a.db_amin : 10.0f * log10f(acc[r]);
-                lm[(size_t)t * a.mp + m] = v;
-                lmax = fmaxf(lmax, v);
-              }
-            }
+          const f32x4 acc = mel_segment<NC, FPW, FPI>(regions, a, mel_src, g, lane);
+          if (g.kind == 1) {
+            *(f32x4*)(slots + (g.slot * 64 + lane) * 4) = acc;
+          } else if (g.kind == 2) {
+            pend = acc;
+            fin = g;
+          } else {
+            mel_epilogue<FPI>(acc, g, a, lm, f0, T, lane, lmax);
           }
         }
         STAMP(3);  // commit + mel
         __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
         STAMP(4);  // barrier wait
+        if (fin.kind == 2) {  // finish the split row block: add the other waves' partial sums, then log + store
+          for (int pidx = 0; pidx < fin.nparts; ++pidx) pend += *(const f32x4*)(slots + ((fin.slot + pidx) * 64 + lane) * 4);
+          mel_epilogue<FPI>(pend, fin, a, lm, f0, T, lane, lmax);
+        }
       }
     }
     if (PCM == DYSF_PCM_F32 && st == DYSF_OK) {
@@ -594,20 +636,34 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(cons
       const int padc = (int)(a.frame_stride - T);
       for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
     }
+    __syncthreads();  // every wave is done with the MFCC chunk: the scratch below reuses it
     if (prow) {
+      // Cross-lane totals without shuffles: per round the wave parks 18 quantities x 64 lanes in LDS, lane q sums
+      // row q in float64 (conflict-free stride 65), lanes with a sum/sum-of-squares pair finish mean and std.
+      float* scr = lds + wave * (18 * 65 + 3);
+      double* tot = (double*)(lds + NW * (18 * 65 + 3)) + wave * 18;  // 8-byte aligned: NW is even
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int c = wave + i * NW;
+      for (int rnd = 0; rnd < RPW / 3; ++rnd) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double m1 = wave_sum((double)ps[i][j]) / (double)T;
-          const double m2 = wave_sum((double)ps[i][3 + j]) / (double)T;
-          if (c < C && lane == 0) {
+        for (int q = 0; q < 18; ++q) scr[q * 65 + lane] = ps[rnd * 3 + q / 6][q % 6];
+        wave_lds_sync();
+        if (lane < 18) {
+          double sum = 0.0;
+          for (int l = 0; l < 64; ++l) sum += (double)scr[lane * 65 + l];
+          tot[lane] = sum;
+        }
+        wave_lds_sync();
+        if (lane < 18 && (lane % 6) < 3) {
+          const int i = rnd * 3 + lane / 6, j = lane % 6;
+          const int c = wave + i * NW;
+          if (c < C) {
+            const double m1 = tot[lane] / (double)T, m2 = tot[lane + 3] / (double)T;
             const double var = m2 - m1 * m1;
             prow[j * 2 * C + c] = (float)((double)kshift[c * 3 + j] + m1);
             prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
           }
         }
+        wave_lds_sync();
       }
     }
     __syncthreads();
@@ -641,7 +697,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(cons
       __syncthreads();
 
       // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the waves)
-      float* part = misc + kMiscChroma;     // [NW][CB][16 rows][16 cols]
+      float* part = misc + kMiscSlots + a.mel_slots * 256;  // [NW][CB][16 rows][16 cols]
       float* raw = part + NW * CB * 256;    // [16][CB*16]
       const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
       double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c

@@ -176,6 +176,7 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
       }
     }
     t.mel_pack = pack_rows(t.mel, p.n_mels, t.n_bins, true);
+    t.mel_pack.data.resize(t.mel_pack.data.size() + 8 * 64, 0.f);  // slack for the kernel's batched tap reads
   }
   // DCT-II ortho rows
   {
