@@ -45,9 +45,6 @@ struct DysfHandle {
   HostTables t;
   int device = -1;
   int num_cu = 256;
-  int threads = 512;      // workgroup shape (DYSF_THREADS=256|512 overrides; see run_dev)
-  int force_logmel = 0;   // DYSF_LOGMEL=global forces the workspace variant
-  unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   size_t lds_limit = 163840;
   // device tables
   float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr, *d_mel_pack = nullptr,
@@ -55,10 +52,12 @@ struct DysfHandle {
   double* d_dct_pack = nullptr;
   int* d_mel_meta = nullptr;
   // workspace / staging
-  DevBuf ws_logmel, ws_peak_mag, ws_peak_bin;
+  DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
+  size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
+  bool sched_built = false;
   DevBuf st_pcm, st_off, st_pooled, st_frames, st_status, st_tuning;
   DevBuf d_mel_sched;
-  int sched_threads = 0, mel_slots = 0;
+  int mel_slots = 0;
 };
 
 template <typename T>
@@ -96,8 +95,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   const char* err = "";
   if (!build_tables(*p, h->t, &err)) { delete h; return fail(DYSF_E_INVALID, err); }
   h->device = device;
-  if (const char* e = std::getenv("DYSF_THREADS")) { if (std::atoi(e) == 512) h->threads = 512; else if (std::atoi(e) == 256) h->threads = 256; }
-  if (const char* e = std::getenv("DYSF_LOGMEL")) { if (std::string(e) == "global") h->force_logmel = 1; }
+  if (const char* e = std::getenv("DYSF_WS_MB")) { if (std::atoll(e) > 0) h->ws_budget = (size_t)std::atoll(e) << 20; }
   if (device >= 0) {
     int rc = 0;
     hipError_t e = hipSetDevice(device);
@@ -126,7 +124,7 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
     (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack);
     (void)hipFree(h->d_chroma_pack);
-    h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release();
+    h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release();
   }
@@ -160,17 +158,6 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
   return n;
 }
 
-#ifdef DYSF_STAMP
-// diagnostic build only (not declared in dysf_hip.h): per-phase cycle sums of wave 0 [0..15] and the last wave [16..31]
-int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out32, int32_t reset) {
-  if (!h || h->device < 0) return DYSF_E_INVALID;
-  if (!h->dbg_stamps) { if (hipMalloc((void**)&h->dbg_stamps, 32 * 8) != hipSuccess) return DYSF_E_HIP; (void)hipMemset(h->dbg_stamps, 0, 32 * 8); }
-  (void)hipDeviceSynchronize();
-  if (out32) (void)hipMemcpy(out32, h->dbg_stamps, 32 * 8, hipMemcpyDeviceToHost);
-  if (reset) (void)hipMemset(h->dbg_stamps, 0, 32 * 8);
-  return 0;
-}
-#endif
 
 }  // extern "C"
 
@@ -243,89 +230,93 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
 
   KArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.pcm = d_pcm; a.offsets = (const long long*)d_offsets; a.n_clips = n_clips;
-  a.pooled = d_pooled; a.pooled_dim = dysf_pooled_dim(h); a.frames = d_frames; a.frame_stride = frame_stride;
-  a.status = d_status; a.tuning = d_tuning; a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel;
-  a.dbg_stamps = h->dbg_stamps;
-  a.sr = p.sr; a.hop = p.hop; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
+  a.pcm = d_pcm; a.hop = p.hop; a.sr = p.sr; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
+  a.pooled_dim = dysf_pooled_dim(h); a.frame_stride = frame_stride;
+  a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel;
   a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
-  int mp = p.n_mels;
-  while (mp % 32 != 2) ++mp;
-  a.mp = mp;
   a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
-  a.mel_pack = h->d_mel_pack; a.mel_meta = h->d_mel_meta; a.mel_rb = t.mel_pack.row_blocks; a.mel_max_steps = t.mel_pack.max_steps;
+  a.mel_pack = h->d_mel_pack;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_steps = t.dct_pack.max_steps;
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
 
-  // LDS carve-up (floats).  Two shapes: 256-thread workgroups with the clip's log-mel in a per-workgroup
-  // global workspace (small LDS footprint -> several workgroups per CU hide each other's barriers and LDS
-  // latency), or 512-thread workgroups that keep the log-mel in LDS (one workgroup per CU).
-  int threads = h->threads;
-  const int nw = threads / 64;
-  const int fpi = t.FPW * nw;
+  // ---- kernel A geometry: small workgroups, several per CU
+  const int nt_a = stft_threads(t.NC), nw_a = nt_a / 64;
+  const int fpi_a = t.FPW * nw_a, cb_a = (fpi_a + 15) / 16;
   int rstride = std::max(t.FPW * (t.NC + t.NC / 16), t.FPW * t.kpad);
   while (rstride % 32 != 8) ++rstride;
   a.rstride = rstride;
-  const int tile_samples = ((fpi - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
-  const int cb = (fpi + 15) / 16;
-  if (h->sched_threads != threads) {
+  if (!h->sched_built) {
     std::vector<int32_t> sched;
-    build_mel_schedule(t, nw, cb, sched, &h->mel_slots);
+    build_mel_schedule(t, nw_a, cb_a, sched, &h->mel_slots);
     if (int rc = h->d_mel_sched.reserve(sched.size() * 4)) return rc;
     HIPCHK(hipMemcpy(h->d_mel_sched.p, sched.data(), sched.size() * 4, hipMemcpyHostToDevice));
-    h->sched_threads = threads;
+    h->sched_built = true;
   }
   a.mel_sched = (const int*)h->d_mel_sched.p;
   a.mel_slots = h->mel_slots;
-  const int misc = kMiscBaseFloats + h->mel_slots * 256 + (p.chroma ? nw * cb * 256 + 16 * cb * 16 : 0);
-  const int tables = (2 * t.NC + t.NC + 2 + 3) & ~3;
-  a.lds_region = 0;
-  a.lds_pcm = nw * rstride;
-  a.lds_misc = a.lds_pcm + tile_samples;
-  a.lds_tables = a.lds_misc + misc;
-  a.lds_logmel = a.lds_tables + tables;
-  {  // phase B reuses [0, lds_misc): MFCC chunk first, then the float64 DCT operands if they fit
-    const int chunk_floats = ((t.cpad * (16 * nw + 1) + 3) & ~3);
-    const int dct_floats = t.dct_pack.row_blocks * t.dct_pack.max_steps * 64 * 2;
-    if (chunk_floats > a.lds_misc) return fail(DYSF_E_INVALID, "internal: MFCC chunk does not fit the LDS scratch");
-    a.lds_dct = (chunk_floats + dct_floats <= a.lds_misc) ? chunk_floats : -1;
+  a.tiles_per_wg = 4;
+  a.tpad = (int)((t_max + 15) & ~(int64_t)15);
+  a.ws_logmel_stride = (int64_t)p.n_mels * a.tpad;
+  a.peak_tile_cap = p.chroma ? fpi_a * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
+  a.ws_peak_stride = p.chroma ? t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
+  const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * t.L + 3) & ~3;
+  const int tile_a = ((fpi_a - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
+  const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 2 * a.peak_tile_cap + 3) & ~3;
+  const int lds_a_region = 0, lds_a_pcm = nw_a * rstride, lds_a_misc = lds_a_pcm + tile_a, lds_a_tables = lds_a_misc + misc_a;
+  const size_t lds_a = (size_t)(lds_a_tables + tables) * 4;
+  if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+
+  // ---- kernel C geometry (chroma): 512 threads, one workgroup per clip
+  const int nw_c = 8, fpi_c = t.FPW * nw_c, cb_c = (fpi_c + 15) / 16;
+  const int tile_c = ((fpi_c - 1) * p.hop + p.n_fft + 8 + 7) & ~7;
+  const int misc_c = (128 + nw_c * cb_c * 256 + 16 * cb_c * 16 + 3) & ~3;
+  const int lds_c_pcm = nw_c * rstride, lds_c_misc = lds_c_pcm + tile_c, lds_c_tables = lds_c_misc + misc_c;
+  const size_t lds_c = (size_t)(lds_c_tables + tables) * 4;
+  if (p.chroma && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+
+  // ---- kernel B LDS: frame-0 features, float64 DCT operands, MFCC chunk (the final reduction reuses the last two)
+  const int nd = t.dct_pack.row_blocks * t.dct_pack.max_steps * 64;
+  const size_t lds_b = (size_t)(kMfccHead + std::max(2 * nd + t.cpad * 129, 8 * (18 * 65 + 3) + 2 * 8 * 18)) * 4;
+
+  // ---- per-clip workspace; very large batches run as several sub-batches that reuse it
+  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8;
+  const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(h->ws_budget / per_clip)));
+  if (int rc = h->ws_logmel.reserve((size_t)sub * a.ws_logmel_stride * 4)) return rc;
+  if (int rc = h->ws_small.reserve((size_t)sub * 12)) return rc;
+  if (p.chroma) {
+    if (int rc = h->ws_peak_mag.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
+    if (int rc = h->ws_peak_bin.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
   }
-  const size_t fixed_bytes = (size_t)a.lds_logmel * 4;
-  if (fixed_bytes > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
-  bool lm_lds = (threads == 512) && fixed_bytes + (size_t)t_max * mp * 4 <= h->lds_limit;
-  if (h->force_logmel == 1) lm_lds = false;
-  size_t lds_bytes = lm_lds ? fixed_bytes + (size_t)t_max * mp * 4 : fixed_bytes;
-  // the packed mel taps live in LDS for the whole kernel when that does not cost a resident workgroup
-  a.mel_pack_floats = (int)t.mel_pack.data.size();
-  a.lds_melpack = -1;
-  {
-    const size_t with_pack = (((lds_bytes / 4 + 3) & ~(size_t)3) + a.mel_pack_floats) * 4;
-    const size_t budget = lm_lds ? h->lds_limit : h->lds_limit / (threads == 256 ? 3 : 2);
-    if (with_pack <= budget) {
-      a.lds_melpack = (int)((lds_bytes / 4 + 3) & ~(size_t)3);
-      lds_bytes = with_pack;
+  a.ws_logmel = (float*)h->ws_logmel.p;
+  a.ws_peak_mag = (float*)h->ws_peak_mag.p;
+  a.ws_peak_bin = (int*)h->ws_peak_bin.p;
+  const int tiles_max = (int)((t_max + fpi_a - 1) / fpi_a);
+  const int groups = (tiles_max + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  if (std::getenv("DYSF_VERBOSE"))
+    std::fprintf(stderr, "[dysf] stft: %d thr, grid %dx%lld, lds %zu B | mfcc: lds %zu B | chroma: lds %zu B | sub-batch %lld clips, slots %d\n",
+                 nt_a, groups, (long long)sub, lds_a, lds_b, p.chroma ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
+
+  for (int64_t c0 = 0; c0 < n_clips; c0 += sub) {
+    const int nc = (int)std::min<int64_t>(sub, n_clips - c0);
+    a.offsets = (const long long*)d_offsets + c0;
+    a.n_clips = nc;
+    a.pooled = d_pooled ? d_pooled + (size_t)c0 * a.pooled_dim : nullptr;
+    a.frames = d_frames ? d_frames + (size_t)c0 * 3 * p.n_mfcc * frame_stride : nullptr;
+    a.status = d_status ? d_status + c0 : nullptr;
+    a.tuning = d_tuning ? d_tuning + c0 : nullptr;
+    a.ws_clipmax = (unsigned*)h->ws_small.p;
+    a.ws_flags = (int*)h->ws_small.p + sub;
+    a.ws_peak_cnt = (int*)h->ws_small.p + 2 * sub;
+    HIPCHK(hipMemsetAsync(h->ws_small.p, 0, (size_t)sub * 12, stream));
+    a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
+    HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
+    HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
+    if (p.chroma) {
+      a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
+      HIPCHK(launch_chroma(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
     }
   }
-  int wg_per_cu = 1;
-  if (!lm_lds) wg_per_cu = std::max<int>(1, std::min<int>(threads == 256 ? 3 : 1, (int)(h->lds_limit / lds_bytes)));
-  const int grid = std::min(n_clips, h->num_cu * wg_per_cu);
-  if (!lm_lds) {
-    if (int rc = h->ws_logmel.reserve((size_t)grid * t_max * mp * 4)) return rc;
-    a.ws_logmel = (float*)h->ws_logmel.p;
-    a.ws_logmel_stride = t_max * mp;
-  }
-  if (p.chroma) {
-    const int64_t cap = t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2);
-    if (int rc = h->ws_peak_mag.reserve((size_t)grid * cap * 4)) return rc;
-    if (int rc = h->ws_peak_bin.reserve((size_t)grid * cap * 4)) return rc;
-    a.ws_peak_mag = (float*)h->ws_peak_mag.p;
-    a.ws_peak_bin = (int*)h->ws_peak_bin.p;
-    a.ws_peak_stride = cap;
-  }
-  if (std::getenv("DYSF_VERBOSE"))
-    std::fprintf(stderr, "[dysf] threads %d grid %d lds %zu B (limit %zu) logmel %s melpack %s dct %s slots %d tile %d floats\n", threads, grid, lds_bytes, h->lds_limit, lm_lds ? "lds" : "global", a.lds_melpack >= 0 ? "lds" : "global", a.lds_dct >= 0 ? "lds" : "global", a.mel_slots, tile_samples);
-  HIPCHK(launch_clip_kernel(a, p.n_fft, threads, pcm_type, lm_lds, grid, lds_bytes, stream));
   return 0;
 }
 

@@ -21,44 +21,49 @@ struct KArgs {
   int* tuning;
   float* dbg_S;       // [T][n_bins] of clip 0 (single-clip debug launches only)
   float* dbg_logmel;  // [T][n_mels]
-  unsigned long long* dbg_stamps;  // [32] cycle sums, DYSF_STAMP builds only
   // parameters
-  int sr, hop, kpad, n_mels, mp, n_mfcc;
+  int sr, hop, kpad, n_mels, n_mfcc;
   float top_db, amin, db_amin;
   int chroma;
-  int rstride;  // floats per wave region (FFT exchange + power-spectrum rows)
+  int rstride;       // floats per wave region (FFT exchange + power-spectrum rows)
+  int tiles_per_wg;  // kernel A: consecutive frame tiles one workgroup processes
   // tables
-  const float* window;
+  const float* window;    // pre-scaled by 1/2
   const float* stage_tw;
   const float* post_tw;
   const float* mel_pack;
-  const int* mel_meta;
-  int mel_rb, mel_max_steps;
-  const int* mel_sched;  // per wave kMelSchedStride ints (see below)
-  int mel_slots;         // split-K partial tiles kept in LDS
+  const int* mel_sched;   // per wave kMelSchedStride ints (see below)
+  int mel_slots;          // split-K partial tiles kept in LDS
   const double* dct_pack;  // float64 A operands
   int dct_rb, dct_steps;
   const float* chroma_pack;
   int chroma_steps;
   int pip_kmin, pip_kmax;
-  // per-workgroup global workspace
-  float* ws_logmel;
-  long long ws_logmel_stride;
+  // per-clip global workspace
+  float* ws_logmel;            // [clip][n_mels][tpad] log-mel (dB, un-clamped)
+  long long ws_logmel_stride;  // floats per clip
+  int tpad;                    // row stride of the log-mel (multiple of 16 floats)
+  unsigned* ws_clipmax;        // [clip] order-preserving encoding of the clip's log-mel maximum (atomicMax)
+  int* ws_flags;               // [clip] 1: non-finite sample seen
+  int* ws_peak_cnt;            // [clip] piptrack peaks appended so far
   float* ws_peak_mag;
   int* ws_peak_bin;
-  long long ws_peak_stride;
-  // LDS carve-up (float offsets)
-  int lds_region, lds_pcm, lds_logmel, lds_misc, lds_tables;
-  int lds_melpack, mel_pack_floats;  // float offset of the kernel-lifetime LDS copy of mel_pack, or -1
-  int lds_dct;  // float offset of the phase-B copy of dct_pack, or -1 to read it from global memory
+  long long ws_peak_stride;    // peak capacity per clip
+  int peak_tile_cap;           // peak capacity of one tile (LDS staging in kernel A)
+  // LDS carve-up (float offsets) of the kernel being launched
+  int lds_region, lds_pcm, lds_misc, lds_tables;
 };
 
 constexpr int kMelMaxSeg = 4;
 constexpr int kMelSchedStride = 40;  // ints per wave: kMelMaxSeg x {rb, cb, kbeg, nsteps, poff, kind, slot, nparts}, nseg at [32]
-constexpr int kMiscBaseFloats = 288 + 8 * kMelSchedStride;  // fixed part of the misc LDS area (see dysf_kernels.hip)
+constexpr int kStftMiscBase = 32 + 8 * kMelSchedStride;  // kernel A misc area before the split-K slots
+constexpr int kMfccHead = 144;                           // kernel B: frame-0 features ahead of the DCT operands
 
-// threads: 256 (4 waves, several workgroups per CU, log-mel in the global workspace) or 512 (8 waves)
-hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int threads, int pcm_type, bool lm_lds, int grid,
-                              size_t lds_bytes, hipStream_t s);
+// kernel A workgroup size: 16 frames per tile up to n_fft 1024, 8 frames at n_fft 2048
+constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
+
+hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 
 }  // namespace dysf

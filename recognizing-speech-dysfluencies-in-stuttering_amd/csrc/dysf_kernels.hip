@@ -1,16 +1,16 @@
 // dysf_kernels.hip -- gfx950 kernels for the dysfluency feature path.
 //
-// One persistent 512-thread workgroup per clip runs the whole of
-//   librosa.feature.mfcc -> delta -> delta(order=2) -> stat_pair  (+ chroma_stft)   pipeline1.py:216-228
-// without leaving the CU:
-//   phase A  per tile of frames: coalesced PCM -> LDS tile; per-wave register FFT (dysf_fft.hpp) ->
-//            power spectrum tile in LDS; banded Slaney-mel GEMM on v_mfma_f32_16x16x4_f32; 10*log10 ->
-//            log-mel [T][n_mels] kept in LDS (global workspace only when a clip is too long);
-//            optional piptrack peak picking for the tuning estimate
-//   phase B  clip-global top_db clamp, DCT-II on the float64 MFMA, Savitzky-Golay deltas, frame-level rows
-//            [3*n_mfcc][T] and pooled mean/std (float64 accumulators)
-//   phase C  (chroma only) median / histogram tuning decision, second STFT pass, chroma GEMM on MFMA
-//            against the selected one of 100 banks, per-frame max normalisation, mean/std
+// librosa.feature.mfcc -> delta -> delta(order=2) -> stat_pair (+ chroma_stft), pipeline1.py:216-228, as three
+// kernels on one stream.  The only HBM intermediate is the log-mel spectrogram (clip-global top_db needs the
+// whole clip before the DCT); everything else lives in registers and LDS.
+//   dysf_stft_mel_kernel  grid (tile groups, clips), small LDS footprint -> 3-4 workgroups per CU:
+//            coalesced PCM -> LDS tile; per-wave register FFT (dysf_fft.hpp) -> power-spectrum tile in LDS;
+//            banded Slaney-mel GEMM on v_mfma_f32_16x16x4_f32 (split-K schedule); 10*log10 -> log-mel
+//            [n_mels][T] in the workspace; clip max by atomicMax; optional piptrack peak picking
+//   dysf_mfcc_kernel      one workgroup per clip: clip-global top_db clamp, DCT-II on the float64 MFMA,
+//            Savitzky-Golay deltas, frame-level rows [3*n_mfcc][T], pooled mean/std
+//   dysf_chroma_kernel    (chroma only) one workgroup per clip: median / histogram tuning decision, second
+//            STFT pass, chroma GEMM on MFMA against the selected one of 100 banks, max-norm, mean/std
 #include <hip/hip_runtime.h>
 
 #include "dysf_fft.hpp"
@@ -128,21 +128,6 @@ __device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile,
   return bad;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Per-lane constants of the wave FFT: stage-1 twiddles stay in registers; the window and the
-// real-spectrum twiddles are read from small LDS tables (consecutive lanes -> consecutive words).
-template <int NC>
-struct FftConsts {
-  cf t1[kPts];
-};
-
-template <int NC>
-__device__ __forceinline__ void load_fft_consts(FftConsts<NC>& c, const KArgs& a, int ls) {
-  const cf* tw = (const cf*)a.stage_tw + ls * kPts;
-#pragma unroll
-  for (int p = 0; p < kPts; ++p) c.t1[p] = tw[p];
-}
-
 // Two-pass (re, then im) transpose of a lane's 16 points through the frame's exchange buffer.
 template <int NC, int SPREV>
 __device__ __forceinline__ void fft_exchange(cf* z, float* xb, int ls) {
@@ -160,10 +145,32 @@ __device__ __forceinline__ void fft_exchange(cf* z, float* xb, int ls) {
 // Windowed frame (in the LDS PCM tile at float offset frame_off) -> power spectrum row srow[0..NC].
 // xb and srow both live in the calling wave's private LDS region.  win holds the window pre-scaled by 1/2
 // (see rfft_pair_power), ptw the un-packing twiddles V[k].
+struct FftTabs {     // LDS tables shared by the workgroup (consecutive lanes -> consecutive words)
+  const float* win;  // [2*NC] window, pre-scaled by 1/2
+  const float* ptw;  // [NC/2+1][2] un-packing twiddles V[k]
+  const cf* t1;      // [16][L] stage-1 twiddles, point-major
+};
+
+// copy the tables from global memory (once per workgroup)
+template <int NC, int NT>
+__device__ __forceinline__ void load_fft_tabs(float* dst, const KArgs& a, FftTabs& t) {
+  constexpr int L = FftGeom<NC>::L;
+  float* win = dst;
+  float* ptw = win + 2 * NC;
+  cf* t1 = (cf*)(ptw + ((NC + 2 + 3) & ~3));
+  for (int i = threadIdx.x; i < 2 * NC; i += NT) win[i] = a.window[i];
+  for (int i = threadIdx.x; i < NC + 2; i += NT) ptw[i] = a.post_tw[i];
+  for (int i = threadIdx.x; i < kPts * L; i += NT) t1[i] = ((const cf*)a.stage_tw)[(i % L) * kPts + (i / L)];
+  t.win = win; t.ptw = ptw; t.t1 = t1;
+}
+template <int NC>
+constexpr int fft_tabs_floats() { return 2 * NC + ((NC + 2 + 3) & ~3) + 2 * kPts * FftGeom<NC>::L; }
+
 template <int NC>
 __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_off, float* xb, float* srow,
-                                                 int ls, const FftConsts<NC>& c, const KArgs& a,
-                                                 const float* win /*LDS [2*NC]*/, const float* ptw /*LDS [NC/2+1][2]*/) {
+                                                 int ls, const FftTabs& tb, const KArgs& a) {
+  const float* win = tb.win;
+  const float* ptw = tb.ptw;
   using G = FftGeom<NC>;
   constexpr int L = G::L;
   constexpr int LAST = G::NSTAGE - 1;
@@ -176,7 +183,12 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
   }
   fft_stage<NC, 0>(z, nullptr);
   fft_exchange<NC, 0>(z, xb, ls);
-  fft_stage<NC, 1>(z, c.t1);
+  {
+    cf t1[kPts];
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) t1[p] = tb.t1[p * L + ls];
+    fft_stage<NC, 1>(z, t1);
+  }
   if (G::NSTAGE == 3) {
     fft_exchange<NC, 1>(z, xb, ls);
     cf t2[kPts];
@@ -218,7 +230,8 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
 // local maximum above 0.1*max in [pip_kmin, pip_kmax) to the workgroup's peak list.
 template <int NC>
 __device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool frame_valid, const KArgs& a,
-                                            float* peak_mag, int* peak_bin, int* peak_count, int peak_cap) {
+                                            float* peak_mag /*LDS*/, int* peak_bin /*LDS*/, int* peak_count /*LDS*/,
+                                            int peak_cap) {
   constexpr int L = FftGeom<NC>::L;
   float mx = 0.f;
   for (int k = ls; k <= NC; k += L) mx = fmaxf(mx, srow[k]);
@@ -317,7 +330,7 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   return acc0 + acc1;
 }
 
-// 10*log10 of a finished mel tile -> log-mel rows, running max
+// 10*log10 of a finished mel tile -> log-mel [n_mels][tpad] rows of the clip (64-byte row segments), running max
 template <int FPI>
 __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const KArgs& a, float* lm, int f0, int T,
                                              int lane, float& lmax) {
@@ -332,7 +345,7 @@ __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const K
         // the host-computed float32(10*log10(amin)) (-100 exactly for 1e-10) so that silent cells are exact.
         const float l2 = __builtin_amdgcn_logf(acc[r]);
         const float v = (acc[r] <= a.amin) ? a.db_amin : fmaf(l2, 3.0102999566398120f - 3.01029992103576660f, l2 * 3.01029992103576660f);
-        lm[(size_t)t * a.mp + m] = v;
+        lm[(size_t)m * a.tpad + t] = v;
         lmax = fmaxf(lmax, v);
       }
     }
@@ -340,485 +353,500 @@ __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const K
 }
 
 // ---------------------------------------------------------------------------------------------
-// misc LDS area (float offsets)
-constexpr int kMiscWaveMax = 0;    // [16] per-wave running max of the log-mel
-constexpr int kMiscBad = 16;       // int: non-finite sample seen
-constexpr int kMiscPeakCnt = 17;   // int: peaks appended so far
-constexpr int kMiscScratch = 18;   // int: block_select counter
-constexpr int kMiscShift = 32;     // float[48][3]: frame-0 features (shift of the one-pass variance)
-constexpr int kMiscHist = 176;     // int[100]: tuning histogram
-constexpr int kMiscSched = 288;    // int[NW][kMelSchedStride] mel schedule (NW <= 8)
-constexpr int kMiscSlots = 288 + 8 * kMelSchedStride;    // mel split-K partial tiles: nslots x 64 lanes x 4 floats; chroma partials follow
+// order-preserving float <-> uint (for atomicMax on the clip's running log-mel maximum)
+__device__ __forceinline__ unsigned enc_ordered(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
 
 #ifdef DYSF_STAMP
-// diagnostic build only: lane 0 of the first and last wave add the cycles since their previous stamp to slot i
-#define STAMP(i)                                                                                         \
-  do {                                                                                                   \
-    if (lane == 0 && (wave == 0 || wave == NW - 1) && a.dbg_stamps) {                                    \
-      const unsigned long long now_ = __builtin_readcyclecounter();                                      \
-      atomicAdd(&a.dbg_stamps[(wave == 0 ? 0 : 16) + (i)], now_ - stamp_last);                           \
-      stamp_last = now_;                                                                                 \
-    }                                                                                                    \
-  } while (0)
+#define STAMP(i) do {} while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int NC, int PCM, bool LM_LDS, int NT>
-__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void dysf_clip_kernel(const KArgs a) {
+// =============================================================================================
+// Kernel A: PCM -> STFT power -> mel -> dB.  grid = (tile groups, clips); NT threads, NT/64 waves.
+template <int NC, int PCM, int NT>
+__global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(const KArgs a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L, FPW = G::FPW;
   constexpr int NW = NT / 64;
   constexpr int FPI = FPW * NW;  // frames per tile
+  constexpr int EPG = PcmStage<PCM>::EPG;
+  extern __shared__ __align__(16) float lds[];
+  float* regions = lds + a.lds_region;
+  float* tile = lds + a.lds_pcm;
+  float* misc = lds + a.lds_misc;   // [0..15] wave max, [16] peak count (int), then schedule, slots, peak stage
+  int* imisc = (int*)misc;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane / L, ls = lane % L;
+  const int clip = blockIdx.y;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  const int ti0 = blockIdx.x * a.tiles_per_wg;
+  if (n <= 0 || T < 9 || ti0 * FPI >= T) return;  // rejected clips and empty tile groups (uniform exit)
+  const int ntiles = min(a.tiles_per_wg, (T - ti0 * FPI + FPI - 1) / FPI);
+
+  float* wregion = regions + wave * a.rstride;
+  float* xb = wregion + q * G::XSTRIDE;
+  float* srow_own = wregion + q * a.kpad;
+  FftTabs tb;
+  load_fft_tabs<NC, NT>(lds + a.lds_tables, a, tb);
+  int* sched = imisc + 32;
+  for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
+  const int* wsched = sched + wave * kMelSchedStride;
+  float* slots = misc + 32 + 8 * kMelSchedStride;
+  float* pk_mag = slots + a.mel_slots * 256;            // chroma only: this tile's peaks
+  int* pk_bin = (int*)(pk_mag + a.peak_tile_cap);
+  if (tid == 0) imisc[16] = 0;
+  f32x4 pend = {0.f, 0.f, 0.f, 0.f};
+  float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
+
+  float lmax = -INFINITY;
+  bool bad = false;
+  const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+  PcmStage<PCM> stage;
+  auto tile_geom = [&](int ti, long long* a0, int* shift, int* ngroups) {
+    const long long s0 = (long long)ti * FPI * a.hop - NC;
+    *a0 = pcm_tile_origin<PCM>(off, s0);
+    *shift = (int)(off + s0 - *a0);
+    *ngroups = (int)((off + s0 + tile_samples - *a0 + EPG - 1) / EPG);
+  };
+  long long a0 = 0;
+  int shift = 0, ngroups = 0;
+  tile_geom(ti0, &a0, &shift, &ngroups);
+  pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
+  bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const int f0 = (ti0 + j) * FPI;
+    const int cur_shift = shift;
+    if (j + 1 < ntiles) {  // loads for the next tile fly while this one is transformed
+      tile_geom(ti0 + j + 1, &a0, &shift, &ngroups);
+      pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
+    }
+    {
+      const int fl = wave * FPW + q;  // frame within tile
+      wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
+      if (a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
+    }
+    __syncthreads();  // S tile complete; every wave is done reading the PCM tile
+    if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
+    if (a.dbg_S) {
+      for (int i = tid; i < FPI * (NC + 1); i += NT) {
+        const int f = i / (NC + 1), k = i % (NC + 1);
+        if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
+      }
+    }
+    if (a.chroma) {  // flush this tile's peaks to the clip's list: one global atomic per tile
+      int* gcnt = a.ws_peak_cnt + clip;
+      const int cnt = min(imisc[16], a.peak_tile_cap);
+      __shared__ int gbase;
+      if (tid == 0) gbase = atomicAdd(gcnt, cnt);
+      __syncthreads();
+      float* gm = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
+      int* gb = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
+      for (int i = tid; i < cnt; i += NT)
+        if (gbase + i < a.ws_peak_stride) { gm[gbase + i] = pk_mag[i]; gb[gbase + i] = pk_bin[i]; }
+      __syncthreads();
+      if (tid == 0) imisc[16] = 0;
+    }
+    // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16], following this wave's
+    // slice of the host-built schedule (row blocks with long bands are split along K over several waves)
+    MelSeg fin;
+    fin.kind = 0;
+    const int nseg = wsched[kMelMaxSeg * 8];
+    for (int i = 0; i < nseg; ++i) {
+      MelSeg g;
+      {
+        const int4 lo = *(const int4*)(wsched + i * 8), hi = *(const int4*)(wsched + 4 + i * 8);
+        g.rb = lo.x; g.cb = lo.y; g.kbeg = lo.z; g.nsteps = lo.w; g.poff = hi.x; g.kind = hi.y; g.slot = hi.z; g.nparts = hi.w;
+      }
+      const f32x4 acc = mel_segment<NC, FPW, FPI>(regions, a, a.mel_pack, g, lane);
+      if (g.kind == 1) {
+        *(f32x4*)(slots + (g.slot * 64 + lane) * 4) = acc;
+      } else if (g.kind == 2) {
+        pend = acc;
+        fin = g;
+      } else {
+        mel_epilogue<FPI>(acc, g, a, lm, f0, T, lane, lmax);
+      }
+    }
+    __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
+    if (fin.kind == 2) {  // finish the split row block: add the other waves' partial sums, then log + store
+      for (int pidx = 0; pidx < fin.nparts; ++pidx) pend += *(const f32x4*)(slots + ((fin.slot + pidx) * 64 + lane) * 4);
+      mel_epilogue<FPI>(pend, fin, a, lm, f0, T, lane, lmax);
+    }
+  }
+  // clip-global maximum of the log-mel (for the top_db clamp) and the non-finite flag
+  lmax = wave_max(lmax);
+  if (lane == 0) misc[wave] = lmax;
+  if (PCM == DYSF_PCM_F32 && bad) a.ws_flags[clip] = 1;
+  __syncthreads();
+  if (tid == 0) {
+    float m = misc[0];
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, misc[w]);
+    atomicMax(a.ws_clipmax + clip, enc_ordered(m));
+  }
+}
+
+// =============================================================================================
+// Kernel B: log-mel [n_mels][tpad] -> clamp -> DCT (float64 MFMA) -> deltas -> frame rows + pooled statistics.
+// One workgroup per clip, chunks of CH = 16*NW - 16 output frames; every wave runs one 16-frame column tile of the
+// DCT (8 halo frames each side of the chunk), then owns the MFCC rows c = wave, wave + NW, ... (a lane is a frame).
+// Mean / variance are one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane
+// partials across the chunks, one float64 reduction per clip.
+constexpr int kBShift = 0;     // float[48][3]: frame-0 features
+constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-byte aligned)
+
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
+  constexpr int NW = NT / 64;
+  constexpr int COLS = 16 * NW;
+  constexpr int CH = COLS - 16;
+  constexpr int CSTR = COLS + 1;          // LDS row stride of the MFCC chunk
+  constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int clip = blockIdx.x;
+  const int C = a.n_mfcc;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  int st = DYSF_OK;
+  if (n <= 0) st = DYSF_EMPTY;
+  else if (T < 9) st = DYSF_TOO_SHORT;
+  else if (a.ws_flags[clip]) st = DYSF_NONFINITE;
+  float* prow = a.pooled ? a.pooled + (size_t)clip * a.pooled_dim : nullptr;
+  float* frow = a.frames ? a.frames + (size_t)clip * 3 * C * a.frame_stride : nullptr;
+  if (tid == 0 && a.status) a.status[clip] = st;
+  if (st != DYSF_OK) {  // the reference's "except -> zeros" row (pipeline1.py:237-239)
+    if (prow) for (int i = tid; i < a.pooled_dim; i += NT) prow[i] = 0.f;
+    if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += NT) frow[i] = 0.f;
+    if (tid == 0 && a.tuning) a.tuning[clip] = 50;
+    return;
+  }
+  if (tid == 0 && a.tuning && !a.chroma) a.tuning[clip] = 50;
+  const float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
+  const float clip_max = dec_ordered(a.ws_clipmax[clip]);
+  const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
+  if (a.dbg_logmel)
+    for (int i = tid; i < T * a.n_mels; i += NT) a.dbg_logmel[i] = lm[(size_t)(i % a.n_mels) * a.tpad + (i / a.n_mels)];
+
+  float* kshift = lds + kBShift;
+  double* dct = (double*)(lds + kBDct);
+  const int nd = a.dct_rb * a.dct_steps * 64;
+  float* chunk = lds + kBDct + 2 * nd;
+  for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
+  float ps[RPW][6];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += CH) {
+    __syncthreads();
+    {
+      int t = t0 - 8 + wave * 16 + (lane & 15);
+      t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+      const float* lcol = lm + (size_t)(lane >> 4) * a.tpad + t;  // B[k = mel][j = frame]: 16 consecutive frames per mel
+      const double* dp = dct + lane;
+      const int mrem = a.n_mels - (lane >> 4);  // this lane's B row is valid while 4*s < mrem
+      f64x4 acc[3];
+#pragma unroll
+      for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < a.dct_steps; s += 4) {  // dct_steps is a multiple of 4 (n_mels padded to 16)
+        float bf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bf[u] = (4 * (s + u) < mrem) ? lcol[(size_t)(4 * (s + u)) * a.tpad] : floor_db;
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+          if (rb < a.dct_rb) {
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = dp[((size_t)rb * a.dct_steps + s + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double bv = (4 * (s + u) < mrem) ? (double)fmaxf(bf[u], floor_db) : 0.0;
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc[rb], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < 3; ++rb)
+        if (rb < a.dct_rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
+            chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < (CH + 63) / 64; ++sub) {
+      const int t = t0 + sub * 64 + lane;
+      const bool tv = (sub * 64 + lane < CH) && (t < T);
+      int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
+      tc = tv ? tc : 4;
+      const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
+      const int bc = tc - (t0 - 8);             // column of the delta centre
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int c = wave + i * NW;
+        if (c < C) {
+          const float* row = chunk + c * CSTR;
+          const float x = row[bx];
+          float d = 0.f, dd = 0.f;
+          if (tv) {
+            const float xc = row[bc], x2 = xc + xc;
+            const float p1 = row[bc + 1], m1 = row[bc - 1], p2 = row[bc + 2], m2 = row[bc - 2];
+            const float p3 = row[bc + 3], m3 = row[bc - 3], p4 = row[bc + 4], m4 = row[bc - 4];
+            d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) * (1.0f / 60.0f);
+            dd = (28.f * ((p4 + m4) - x2) + 7.f * ((p3 + m3) - x2) - 8.f * ((p2 + m2) - x2) - 17.f * ((p1 + m1) - x2)) *
+                 (1.0f / 462.0f);
+          }
+          if (t0 == 0 && sub == 0) {  // shift values = the features of frame 0
+            if (lane == 0) { kshift[c * 3 + 0] = x; kshift[c * 3 + 1] = d; kshift[c * 3 + 2] = dd; }
+            wave_lds_sync();
+          }
+          if (tv) {
+            const float e0 = x - kshift[c * 3 + 0], e1 = d - kshift[c * 3 + 1], e2 = dd - kshift[c * 3 + 2];
+            ps[i][0] += e0; ps[i][1] += e1; ps[i][2] += e2;
+            ps[i][3] += e0 * e0; ps[i][4] += e1 * e1; ps[i][5] += e2 * e2;
+            if (frow) {
+              frow[(size_t)c * a.frame_stride + t] = x;
+              frow[(size_t)(C + c) * a.frame_stride + t] = d;
+              frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (frow && a.frame_stride > T) {  // zero-fill the padding columns
+    const int padc = (int)(a.frame_stride - T);
+    for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
+  }
+  __syncthreads();  // every wave is done with the MFCC chunk and the DCT operands: the scratch below reuses them
+  if (prow) {
+    // Cross-lane totals without shuffles: per round the wave parks 18 quantities x 64 lanes in LDS, lane q sums
+    // row q in float64 (conflict-free stride 65), lanes with a sum / sum-of-squares pair finish mean and std.
+    float* scr = lds + kBDct + wave * (18 * 65 + 3);
+    double* tot = (double*)(lds + kBDct + NW * (18 * 65 + 3)) + wave * 18;  // 8-byte aligned: NW and kBDct are even
+#pragma unroll
+    for (int rnd = 0; rnd < RPW / 3; ++rnd) {
+#pragma unroll
+      for (int q = 0; q < 18; ++q) scr[q * 65 + lane] = ps[rnd * 3 + q / 6][q % 6];
+      wave_lds_sync();
+      if (lane < 18) {
+        double sum = 0.0;
+        for (int l = 0; l < 64; ++l) sum += (double)scr[lane * 65 + l];
+        tot[lane] = sum;
+      }
+      wave_lds_sync();
+      if (lane < 18 && (lane % 6) < 3) {
+        const int i = rnd * 3 + lane / 6, j = lane % 6;
+        const int c = wave + i * NW;
+        if (c < C) {
+          const double m1 = tot[lane] / (double)T, m2 = tot[lane + 3] / (double)T;
+          const double var = m2 - m1 * m1;
+          prow[j * 2 * C + c] = (float)((double)kshift[c * 3 + j] + m1);
+          prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
+// =============================================================================================
+// Kernel C (chroma presets): tuning decision from the clip's peak list, second STFT pass, chroma GEMM, max-norm,
+// mean / std.  One workgroup per clip.
+template <int NC, int PCM, int NT>
+__global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L, FPW = G::FPW;
+  constexpr int NW = NT / 64;
+  constexpr int FPI = FPW * NW;
   constexpr int CB = (FPI + 15) / 16;
   constexpr int EPG = PcmStage<PCM>::EPG;
   extern __shared__ __align__(16) float lds[];
   float* regions = lds + a.lds_region;
   float* tile = lds + a.lds_pcm;
-  float* lm_lds = lds + a.lds_logmel;
-  float* misc = lds + a.lds_misc;
-  float* win = lds + a.lds_tables;      // [2*NC] window
-  float* ptw = win + 2 * NC;            // [NC/2+1][2] real-spectrum twiddles
+  float* misc = lds + a.lds_misc;  // [0] scratch (int), [16..115] histogram (int), [128..] chroma partial tiles
   int* imisc = (int*)misc;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane / L, ls = lane % L;
+  const int clip = blockIdx.x;
+  const int C = a.n_mfcc;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  if (n <= 0 || T < 9 || a.ws_flags[clip] || !a.pooled) {  // rejected clip: kernel B already wrote the zero row
+    if (tid == 0 && a.tuning) a.tuning[clip] = 50;
+    return;
+  }
   float* wregion = regions + wave * a.rstride;
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * a.kpad;
-
-  // kernel-lifetime LDS tables: window, un-packing twiddles, and (when there is room) the packed mel taps
-  for (int i = tid; i < 2 * NC; i += NT) win[i] = a.window[i];
-  for (int i = tid; i < NC + 2; i += NT) ptw[i] = a.post_tw[i];
-  const float* mel_src = a.mel_pack;
-  if (a.lds_melpack >= 0) {
-    float* ml = lds + a.lds_melpack;
-    for (int i = tid * 4; i < a.mel_pack_floats; i += NT * 4) *(float4*)(ml + i) = *(const float4*)(a.mel_pack + i);
-    mel_src = ml;
+  FftTabs tb;
+  load_fft_tabs<NC, NT>(lds + a.lds_tables, a, tb);
+  float* prow = a.pooled + (size_t)clip * a.pooled_dim;
+  const float* pk_mag = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
+  const int* pk_bin = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
+  int* hist = imisc + 16;
+  int npk = a.ws_peak_cnt[clip];
+  npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
+  __syncthreads();
+  int tune = 50;
+  if (npk > 0) {
+    float thr;
+    if (npk & 1) {
+      thr = block_select<NT>(pk_mag, npk, npk / 2, &imisc[0]);
+    } else {
+      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, &imisc[0]);
+      const float hi = block_select<NT>(pk_mag, npk, npk / 2, &imisc[0]);
+      thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+    }
+    if (tid < kTunings) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < npk; i += NT)
+      if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
+    __syncthreads();
+    int best = 0, bcnt = hist[0];
+    for (int i = 1; i < kTunings; ++i)
+      if (hist[i] > bcnt) { bcnt = hist[i]; best = i; }
+    tune = best;
   }
-  // the mel schedule (host-built, per wave: kMelMaxSeg x 8 ints, then nseg) is copied to LDS once
-  int* sched = (int*)(misc + kMiscSched);
-  for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
-  const int* wsched = sched + wave * kMelSchedStride;
-  float* slots = misc + kMiscSlots;
-  f32x4 pend = {0.f, 0.f, 0.f, 0.f};
-  const int C = a.n_mfcc;
-#ifdef DYSF_STAMP
-  unsigned long long stamp_last = __builtin_readcyclecounter();
-#endif
-  for (int clip = blockIdx.x; clip < a.n_clips; clip += gridDim.x) {
-    const long long off = a.offsets[clip];
-    const long long n = a.offsets[clip + 1] - off;
-    const int T = (int)(1 + n / a.hop);
-    int st = DYSF_OK;
-    if (n <= 0) st = DYSF_EMPTY;
-    else if (T < 9) st = DYSF_TOO_SHORT;
-    float* lm = LM_LDS ? lm_lds : (a.ws_logmel + (size_t)blockIdx.x * a.ws_logmel_stride);
-    float* pk_mag = a.ws_peak_mag ? a.ws_peak_mag + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
-    int* pk_bin = a.ws_peak_bin ? a.ws_peak_bin + (size_t)blockIdx.x * a.ws_peak_stride : nullptr;
-    if (tid < 32) imisc[tid] = 0;
-    __syncthreads();
+  if (tid == 0 && a.tuning) a.tuning[clip] = tune;
+  __syncthreads();
 
-    // ------------------------------------------------------------------ phase A
-    float lmax = -INFINITY;
-    bool bad = false;
-    const int ntiles = (st == DYSF_OK) ? (T + FPI - 1) / FPI : 0;
-    const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+  // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the waves)
+  float* part = misc + 128;             // [NW][CB][16 rows][16 cols]
+  float* raw = part + NW * CB * 256;    // [16][CB*16]
+  const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
+  double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c
+  float cshift = 0.f;
+  const int ntiles = (T + FPI - 1) / FPI;
+  const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int f0 = ti * FPI;
+    const long long cs0 = (long long)f0 * a.hop - NC;
+    const long long ca0 = pcm_tile_origin<PCM>(off, cs0);
     {
-      FftConsts<NC> fc;
-      load_fft_consts<NC>(fc, a, ls);
       PcmStage<PCM> stage;
-      auto tile_geom = [&](int ti, long long* a0, int* shift, int* ngroups) {
-        const long long s0 = (long long)ti * FPI * a.hop - NC;
-        *a0 = pcm_tile_origin<PCM>(off, s0);
-        *shift = (int)(off + s0 - *a0);
-        *ngroups = (int)((off + s0 + tile_samples - *a0 + EPG - 1) / EPG);
-      };
-      long long a0 = 0;
-      int shift = 0, ngroups = 0;
-      if (ntiles > 0) {
-        tile_geom(0, &a0, &shift, &ngroups);
-        pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
-        bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
-      }
-      __syncthreads();
-      STAMP(0);  // clip setup + first tile staged
-      for (int ti = 0; ti < ntiles; ++ti) {
-        const int f0 = ti * FPI;
-        const int cur_shift = shift;
-        if (ti + 1 < ntiles) {  // loads for the next tile fly while this one is transformed
-          tile_geom(ti + 1, &a0, &shift, &ngroups);
-          pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
-        }
-        {
-          const int fl = wave * FPW + q;  // frame within tile
-          wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, fc, a, win, ptw);
-          if (a.chroma)
-            frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[kMiscPeakCnt], (int)a.ws_peak_stride);
-        }
-        STAMP(1);  // FFT
-        __syncthreads();  // S tile complete; every wave is done reading the PCM tile
-        STAMP(2);  // barrier wait
-        if (ti + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
-        if (a.dbg_S) {
-          for (int i = tid; i < FPI * (NC + 1); i += NT) {
-            const int f = i / (NC + 1), k = i % (NC + 1);
-            if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
-          }
-        }
-        // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16], following this wave's
-        // slice of the host-built schedule (row blocks with long bands are split along K over several waves)
-        MelSeg fin;
-        fin.kind = 0;
-        const int nseg = wsched[kMelMaxSeg * 8];
-        for (int i = 0; i < nseg; ++i) {
-          MelSeg g;
-          {
-            const int4 lo = *(const int4*)(wsched + i * 8), hi = *(const int4*)(wsched + 4 + i * 8);
-            g.rb = lo.x; g.cb = lo.y; g.kbeg = lo.z; g.nsteps = lo.w; g.poff = hi.x; g.kind = hi.y; g.slot = hi.z; g.nparts = hi.w;
-          }
-          const f32x4 acc = mel_segment<NC, FPW, FPI>(regions, a, mel_src, g, lane);
-          if (g.kind == 1) {
-            *(f32x4*)(slots + (g.slot * 64 + lane) * 4) = acc;
-          } else if (g.kind == 2) {
-            pend = acc;
-            fin = g;
-          } else {
-            mel_epilogue<FPI>(acc, g, a, lm, f0, T, lane, lmax);
-          }
-        }
-        STAMP(3);  // commit + mel
-        __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
-        STAMP(4);  // barrier wait
-        if (fin.kind == 2) {  // finish the split row block: add the other waves' partial sums, then log + store
-          for (int pidx = 0; pidx < fin.nparts; ++pidx) pend += *(const f32x4*)(slots + ((fin.slot + pidx) * 64 + lane) * 4);
-          mel_epilogue<FPI>(pend, fin, a, lm, f0, T, lane, lmax);
-        }
-      }
-    }
-    if (PCM == DYSF_PCM_F32 && st == DYSF_OK) {
-      // samples no frame touches (hop > n_fft/2 + 1) still invalidate the clip in librosa
-      for (long long s = tid; s < n; s += NT) bad |= !isfinite(((const float*)a.pcm)[off + s]);
-      if (bad) imisc[kMiscBad] = 1;
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0) misc[kMiscWaveMax + wave] = lmax;
-    __syncthreads();
-    if (PCM == DYSF_PCM_F32 && imisc[kMiscBad]) st = DYSF_NONFINITE;
-    float clip_max = misc[kMiscWaveMax];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) clip_max = fmaxf(clip_max, misc[kMiscWaveMax + w]);
-    const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
-
-    if (a.dbg_logmel && st == DYSF_OK)
-      for (int i = tid; i < T * a.n_mels; i += NT)
-        a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.mp + (i % a.n_mels)];
-
-    float* prow = a.pooled ? a.pooled + (size_t)clip * a.pooled_dim : nullptr;
-    float* frow = a.frames ? a.frames + (size_t)clip * 3 * C * a.frame_stride : nullptr;
-    if (tid == 0 && a.status) a.status[clip] = st;
-
-    if (st != DYSF_OK) {  // the reference's "except -> zeros" row (pipeline1.py:237-239)
-      if (prow) for (int i = tid; i < a.pooled_dim; i += NT) prow[i] = 0.f;
-      if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += NT) frow[i] = 0.f;
-      if (tid == 0 && a.tuning) a.tuning[clip] = 50;
-      __syncthreads();
-      continue;
-    }
-
-    // ------------------------------------------------------------------ phase B
-    // Chunks of CH = 16*NW - 16 output frames.  Per chunk every wave runs the float64-MFMA DCT of one 16-frame
-    // column tile (8 halo frames each side of the chunk) against all row blocks, then owns the MFCC rows
-    // c = wave, wave + NW, ... for deltas, stores and statistics (a lane is a frame).  Mean / variance are
-    // one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane partials across
-    // the chunks, one float64 cross-lane reduction per clip.
-    constexpr int COLS = 16 * NW;
-    constexpr int CH = COLS - 16;
-    constexpr int CSTR = COLS + 1;          // LDS row stride of the MFCC chunk
-    constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
-    float* chunk = lds;                      // aliases regions + PCM tile (phase A is over)
-    float* kshift = misc + kMiscShift;
-    const double* dct_src = a.dct_pack;
-    __syncthreads();
-    if (a.lds_dct >= 0) {  // float64 DCT operands into the LDS phase A no longer needs (when they fit)
-      double* dl = (double*)(lds + a.lds_dct);
-      const int nd = a.dct_rb * a.dct_steps * 64;
-      for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dl + i) = *(const double2*)(a.dct_pack + i);
-      dct_src = dl;
-    }
-    float ps[RPW][6];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
-    STAMP(5);  // max reduce, status, phase-B setup
-    for (int t0 = 0; t0 < T; t0 += CH) {
-      __syncthreads();
-      STAMP(6);  // barrier wait
-      {
-        int t = t0 - 8 + wave * 16 + (lane & 15);
-        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-        const float* lrow = lm + (size_t)t * a.mp + (lane >> 4);
-        const double* dp = dct_src + lane;
-        const int mrem = a.n_mels - (lane >> 4);  // this lane's B row is valid while 4*s < mrem
-        f64x4 acc[3];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < a.dct_steps; s += 4) {  // dct_steps is a multiple of 4 (n_mels padded to 16)
-          double bv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            bv[u] = (4 * (s + u) < mrem) ? (double)fmaxf(lrow[4 * (s + u)], floor_db) : 0.0;
-#pragma unroll
-          for (int rb = 0; rb < 3; ++rb) {
-            if (rb < a.dct_rb) {
-              double av[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) av[u] = dp[((size_t)rb * a.dct_steps + s + u) * 64];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[rb], 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-          if (rb < a.dct_rb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
-              chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
-      }
-      STAMP(7);  // DCT
-      __syncthreads();
-      STAMP(8);  // barrier wait
-#pragma unroll
-      for (int sub = 0; sub < (CH + 63) / 64; ++sub) {
-        const int t = t0 + sub * 64 + lane;
-        const bool tv = (sub * 64 + lane < CH) && (t < T);
-        int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
-        tc = tv ? tc : 4;
-        const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
-        const int bc = tc - (t0 - 8);             // column of the delta centre
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-          const int c = wave + i * NW;
-          if (c < C) {
-            const float* row = chunk + c * CSTR;
-            const float x = row[bx];
-            float d = 0.f, dd = 0.f;
-            if (tv) {
-              const float xc = row[bc], x2 = xc + xc;
-              const float p1 = row[bc + 1], m1 = row[bc - 1], p2 = row[bc + 2], m2 = row[bc - 2];
-              const float p3 = row[bc + 3], m3 = row[bc - 3], p4 = row[bc + 4], m4 = row[bc - 4];
-              d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) * (1.0f / 60.0f);
-              dd = (28.f * ((p4 + m4) - x2) + 7.f * ((p3 + m3) - x2) - 8.f * ((p2 + m2) - x2) - 17.f * ((p1 + m1) - x2)) *
-                   (1.0f / 462.0f);
-            }
-            if (t0 == 0 && sub == 0) {  // shift values = the features of frame 0
-              if (lane == 0) { kshift[c * 3 + 0] = x; kshift[c * 3 + 1] = d; kshift[c * 3 + 2] = dd; }
-              wave_lds_sync();
-            }
-            if (tv) {
-              const float e0 = x - kshift[c * 3 + 0], e1 = d - kshift[c * 3 + 1], e2 = dd - kshift[c * 3 + 2];
-              ps[i][0] += e0; ps[i][1] += e1; ps[i][2] += e2;
-              ps[i][3] += e0 * e0; ps[i][4] += e1 * e1; ps[i][5] += e2 * e2;
-              if (frow) {
-                frow[(size_t)c * a.frame_stride + t] = x;
-                frow[(size_t)(C + c) * a.frame_stride + t] = d;
-                frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
-              }
-            }
-          }
-        }
-      }
-    }
-    STAMP(9);  // last chunk's deltas, stats, stores
-    if (frow && a.frame_stride > T) {  // zero-fill the padding columns
-      const int padc = (int)(a.frame_stride - T);
-      for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
-    }
-    __syncthreads();  // every wave is done with the MFCC chunk: the scratch below reuses it
-    if (prow) {
-      // Cross-lane totals without shuffles: per round the wave parks 18 quantities x 64 lanes in LDS, lane q sums
-      // row q in float64 (conflict-free stride 65), lanes with a sum/sum-of-squares pair finish mean and std.
-      float* scr = lds + wave * (18 * 65 + 3);
-      double* tot = (double*)(lds + NW * (18 * 65 + 3)) + wave * 18;  // 8-byte aligned: NW is even
-#pragma unroll
-      for (int rnd = 0; rnd < RPW / 3; ++rnd) {
-#pragma unroll
-        for (int q = 0; q < 18; ++q) scr[q * 65 + lane] = ps[rnd * 3 + q / 6][q % 6];
-        wave_lds_sync();
-        if (lane < 18) {
-          double sum = 0.0;
-          for (int l = 0; l < 64; ++l) sum += (double)scr[lane * 65 + l];
-          tot[lane] = sum;
-        }
-        wave_lds_sync();
-        if (lane < 18 && (lane % 6) < 3) {
-          const int i = rnd * 3 + lane / 6, j = lane % 6;
-          const int c = wave + i * NW;
-          if (c < C) {
-            const double m1 = tot[lane] / (double)T, m2 = tot[lane + 3] / (double)T;
-            const double var = m2 - m1 * m1;
-            prow[j * 2 * C + c] = (float)((double)kshift[c * 3 + j] + m1);
-            prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
-          }
-        }
-        wave_lds_sync();
-      }
+      const int cng = (int)((off + cs0 + tile_samples - ca0 + EPG - 1) / EPG);
+      pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, ca0, cng);
+      pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, ca0, cng);
     }
     __syncthreads();
-
-    // ------------------------------------------------------------------ phase C: chroma
-    if (a.chroma) {
-      int* hist = imisc + kMiscHist;
-      int npk = imisc[kMiscPeakCnt];
-      npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
-      int tune = 50;
-      if (npk > 0) {
-        float thr;
-        if (npk & 1) {
-          thr = block_select<NT>(pk_mag, npk, npk / 2, &imisc[kMiscScratch]);
-        } else {
-          const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, &imisc[kMiscScratch]);
-          const float hi = block_select<NT>(pk_mag, npk, npk / 2, &imisc[kMiscScratch]);
-          thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+    wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, tb, a);
+    __syncthreads();
+    const int sb = (a.chroma_steps * wave) / NW, se = (a.chroma_steps * (wave + 1)) / NW;
+    for (int cb = 0; cb < CB; ++cb) {
+      int f = cb * 16 + (lane & 15);
+      f = f < FPI ? f : FPI - 1;
+      const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      int s = sb;
+      for (; s + 8 <= se; s += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = bank[(s + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = 4 * (s + u) + (lane >> 4);
+          bv[u] = (k <= NC) ? srow[k] : 0.f;
         }
-        if (tid < kTunings) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < npk; i += NT)
-          if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
-        __syncthreads();
-        int best = 0, bcnt = hist[0];
-        for (int i = 1; i < kTunings; ++i)
-          if (hist[i] > bcnt) { bcnt = hist[i]; best = i; }
-        tune = best;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
       }
-      if (tid == 0 && a.tuning) a.tuning[clip] = tune;
-      __syncthreads();
-
-      // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the waves)
-      float* part = misc + kMiscSlots + a.mel_slots * 256;  // [NW][CB][16 rows][16 cols]
-      float* raw = part + NW * CB * 256;    // [16][CB*16]
-      const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
-      double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c
-      float cshift = 0.f;
-      FftConsts<NC> fc;
-      load_fft_consts<NC>(fc, a, ls);
-      for (int ti = 0; ti < ntiles; ++ti) {
-        const int f0 = ti * FPI;
-        const long long cs0 = (long long)f0 * a.hop - NC;
-        const long long ca0 = pcm_tile_origin<PCM>(off, cs0);
-        {
-          PcmStage<PCM> stage;
-          const int cng = (int)((off + cs0 + tile_samples - ca0 + EPG - 1) / EPG);
-          pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, ca0, cng);
-          pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, ca0, cng);
-        }
-        __syncthreads();
-        wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, fc, a, win, ptw);
-        __syncthreads();
-        const int sb = (a.chroma_steps * wave) / NW, se = (a.chroma_steps * (wave + 1)) / NW;
-        for (int cb = 0; cb < CB; ++cb) {
-          int f = cb * 16 + (lane & 15);
-          f = f < FPI ? f : FPI - 1;
-          const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          int s = sb;
-          for (; s + 8 <= se; s += 8) {
-            float av[8], bv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = bank[(s + u) * 64 + lane];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int k = 4 * (s + u) + (lane >> 4);
-              bv[u] = (k <= NC) ? srow[k] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-          }
-          for (; s < se; ++s) {
-            const int k = 4 * s + (lane >> 4);
-            const float bv = (k <= NC) ? srow[k] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bank[s * 64 + lane], bv, acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            part[((wave * CB + cb) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
-        }
-        __syncthreads();
-        for (int i = tid; i < CB * 256; i += NT) {
-          const int cb = i / 256, rc = i % 256;
-          float v = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) v += part[(w * CB + cb) * 256 + rc];
-          raw[(rc / 16) * (CB * 16) + cb * 16 + (rc % 16)] = v;
-        }
-        __syncthreads();
-        if (wave == 0) {
-          // lane c (< 12) walks the tile's frames in order; every lane computes the frame max
-          for (int f = 0; f < FPI && f0 + f < T; ++f) {
-            float mxv = 0.f;
-#pragma unroll
-            for (int c = 0; c < kChroma; ++c) mxv = fmaxf(mxv, fabsf(raw[c * (CB * 16) + f]));
-            const float len = (mxv < 1.17549435e-38f) ? 1.0f : mxv;
-            if (lane < kChroma) {
-              const float v = __fdiv_rn(raw[lane * (CB * 16) + f], len);
-              if (f0 + f == 0) cshift = v;
-              const double e = (double)v - (double)cshift;
-              cs1 += e; cs2 += e * e;
-            }
-          }
-        }
-        // the next staging barrier protects raw/part and the S regions
+      for (; s < se; ++s) {
+        const int k = 4 * s + (lane >> 4);
+        const float bv = (k <= NC) ? srow[k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bank[s * 64 + lane], bv, acc, 0, 0, 0);
       }
-      if (wave == 0 && lane < kChroma && prow) {
-        const double m1 = cs1 / (double)T, m2 = cs2 / (double)T;
-        const double var = m2 - m1 * m1;
-        prow[6 * C + lane] = (float)((double)cshift + m1);
-        prow[6 * C + kChroma + lane] = (float)sqrt(var > 0.0 ? var : 0.0);
-      }
-    } else if (tid == 0 && a.tuning) {
-      a.tuning[clip] = 50;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[((wave * CB + cb) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
     }
     __syncthreads();
+    for (int i = tid; i < CB * 256; i += NT) {
+      const int cb = i / 256, rc = i % 256;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += part[(w * CB + cb) * 256 + rc];
+      raw[(rc / 16) * (CB * 16) + cb * 16 + (rc % 16)] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane c (< 12) walks the tile's frames in order; every lane computes the frame max
+      for (int f = 0; f < FPI && f0 + f < T; ++f) {
+        float mxv = 0.f;
+#pragma unroll
+        for (int c = 0; c < kChroma; ++c) mxv = fmaxf(mxv, fabsf(raw[c * (CB * 16) + f]));
+        const float len = (mxv < 1.17549435e-38f) ? 1.0f : mxv;
+        if (lane < kChroma) {
+          const float v = __fdiv_rn(raw[lane * (CB * 16) + f], len);
+          if (f0 + f == 0) cshift = v;
+          const double e = (double)v - (double)cshift;
+          cs1 += e; cs2 += e * e;
+        }
+      }
+    }
+    // the next staging barrier protects raw/part and the S regions
+  }
+  if (wave == 0 && lane < kChroma) {
+    const double m1 = cs1 / (double)T, m2 = cs2 / (double)T;
+    const double var = m2 - m1 * m1;
+    prow[6 * C + lane] = (float)((double)cshift + m1);
+    prow[6 * C + kChroma + lane] = (float)sqrt(var > 0.0 ? var : 0.0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NC, int NT>
-static hipError_t launch_nt(const KArgs& a, int pcm_type, bool lm_lds, int grid, size_t lds_bytes, hipStream_t s) {
-#define DYSF_LAUNCH(PCMT, LM)                                                                             \
-  do {                                                                                                    \
-    auto kern = dysf_clip_kernel<NC, PCMT, LM, NT>;                                                       \
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                       (int)lds_bytes);                                                   \
-    if (e != hipSuccess) return e;                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, a);                                      \
-    return hipGetLastError();                                                                             \
-  } while (0)
-  if (pcm_type == DYSF_PCM_I16) {
-    if (lm_lds) DYSF_LAUNCH(DYSF_PCM_I16, true); else DYSF_LAUNCH(DYSF_PCM_I16, false);
-  } else {
-    if (lm_lds) DYSF_LAUNCH(DYSF_PCM_F32, true); else DYSF_LAUNCH(DYSF_PCM_F32, false);
-  }
-#undef DYSF_LAUNCH
+template <typename K>
+static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, s, a);
+  return hipGetLastError();
 }
 
 template <int NC>
-static hipError_t launch_nc(const KArgs& a, int threads, int pcm_type, bool lm_lds, int grid, size_t lds_bytes,
-                            hipStream_t s) {
-  if (threads == 256) return launch_nt<NC, 256>(a, pcm_type, lm_lds, grid, lds_bytes, s);
-  if (threads == 512) return launch_nt<NC, 512>(a, pcm_type, lm_lds, grid, lds_bytes, s);
-  return hipErrorInvalidValue;
+static hipError_t launch_stft_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  constexpr int NT = stft_threads(NC);
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT>, grid, NT, lds_bytes, s, a);
+  return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT>, grid, NT, lds_bytes, s, a);
+}
+template <int NC>
+static hipError_t launch_chroma_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_I16, 512>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_F32, 512>, grid, 512, lds_bytes, s, a);
 }
 
-hipError_t launch_clip_kernel(const KArgs& a, int n_fft, int threads, int pcm_type, bool lm_lds, int grid,
-                              size_t lds_bytes, hipStream_t s) {
+hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   switch (n_fft) {
-    case 256: return launch_nc<128>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 512: return launch_nc<256>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 1024: return launch_nc<512>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
-    case 2048: return launch_nc<1024>(a, threads, pcm_type, lm_lds, grid, lds_bytes, s);
+    case 256: return launch_stft_nc<128>(a, pcm_type, grid, lds_bytes, s);
+    case 512: return launch_stft_nc<256>(a, pcm_type, grid, lds_bytes, s);
+    case 1024: return launch_stft_nc<512>(a, pcm_type, grid, lds_bytes, s);
+    case 2048: return launch_stft_nc<1024>(a, pcm_type, grid, lds_bytes, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  return launch_one(dysf_mfcc_kernel<512>, grid, 512, lds_bytes, s, a);
+}
+hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  switch (n_fft) {
+    case 256: return launch_chroma_nc<128>(a, pcm_type, grid, lds_bytes, s);
+    case 512: return launch_chroma_nc<256>(a, pcm_type, grid, lds_bytes, s);
+    case 1024: return launch_chroma_nc<512>(a, pcm_type, grid, lds_bytes, s);
+    case 2048: return launch_chroma_nc<1024>(a, pcm_type, grid, lds_bytes, s);
     default: return hipErrorInvalidValue;
   }
 }
