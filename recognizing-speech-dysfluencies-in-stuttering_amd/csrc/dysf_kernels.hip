@@ -197,20 +197,42 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
     for (int p = 0; p < kPts; ++p) t2[p] = tw2[p];
     fft_stage<NC, 2>(z, t2);
   }
-  // natural-order spectrum through the buffer; gather the (k, NC-k) pairs this lane un-packs
+  // gather the (k, NC-k) bin pairs this lane un-packs: k = ls + L*i, i < 8 (+ the self-paired bin NC/2 in lane 0)
   cf zk[9], zm[9];
+  if (NC == 256) {
+    // two-stage layout: register p of lane ls already holds Z[ls + 16 p], and Z[NC - k] sits in register 15 - i
+    // of lane 16 - ls of the same frame (lane 0 pairs with itself, shifted by one register) -> two DPP moves
+    // per value instead of a round trip through the exchange buffer
+    const unsigned long long lane0 = __ballot(ls == 0);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < 8; ++i) {
+      zk[i] = z[i];
 #pragma unroll
-    for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = z[p][h];
-    wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int k = (i == 8) ? NC / 2 : ls + L * i;
-      zk[i][h] = xb[pad_idx(k)];
-      zm[i][h] = xb[pad_idx((NC - k) % NC)];
+      for (int h = 0; h < 2; ++h) {  // lane ls <- lane (16 - ls) & 15 of its row: row_mirror, then row_ror:1 (two DPP moves)
+        // the select is inline asm on purpose: written as ?: the compiler folds it into a dynamically indexed
+        // register array (a 32-way compare chain per value)
+        float offer;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
+        const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(offer), 0x140, 0xf, 0xf, false);
+        zm[i][h] = __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false));
+      }
     }
-    wave_lds_sync();
+    zk[8] = z[8];
+    zm[8] = z[8];
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = z[p][h];
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int k = (i == 8) ? NC / 2 : ls + L * i;
+        zk[i][h] = xb[pad_idx(k)];
+        zm[i][h] = xb[pad_idx((NC - k) % NC)];
+      }
+      wave_lds_sync();
+    }
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) {

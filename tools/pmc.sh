@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc.sh <outdir-under-gpurun_out> "<counter list>" [bench args]   (run on the GPU box)
+# Collects PMC counters for the dysf kernels of a short bench run (no forks under --pmc: --bank-workers 1).
 set -e
 out=gpurun_out/$1; shift
 ctrs="$1"; shift
@@ -10,8 +11,9 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dysf_clip_kernel" in r["Kernel_Name"]:
-            a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
-for k, (v, n) in sorted(agg.items()):
-    print(f"{k:32s} per-launch {v / n:16.1f}  (launches {n})")
+        if "dysf_" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("dysf::")[1].split("<")[0]
+            a = agg[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for (k, c), (v, n) in sorted(agg.items()):
+    print(f"{k:24s} {c:28s} per-launch {v / n:16.1f}  (launches {n})")
 PY
