@@ -251,3 +251,57 @@ def test_cnn_head_runs_on_frame_features(ex512):
     ref = CNNHead()(ref_in)
     assert torch.equal(res["logits"].argmax(1).cpu(), ref.argmax(1))
     assert float((res["logits"].cpu() - ref.detach()).abs().max()) <= 1e-3
+
+
+def test_config5_variable_length_22k(golden_dir):
+    """BASELINE configs[4] shape: clips of 1-10 s at 22.05 kHz (the rate is just a parameter: no resampling),
+    n_fft 2048 / hop 512 / 128 mels / 20 MFCC + delta + delta2, ragged batch, one launch."""
+    p = rsd_amd.FeatureParams(sr=22050, chroma=True)
+    op = O.FeatureParams(sr=22050)
+    ex = rsd_amd.get_extractor(p, 0)
+    rng = np.random.default_rng(4321)
+    lens = (rng.uniform(1.0, 10.0, size=6) * 22050).astype(int)
+    clips = [synth_clip(100 + i, n=int(n), sr=22050) for i, n in enumerate(lens)]
+    res = ex.extract_batch(clips, frames=True, tuning=True)
+    assert res["status"].tolist() == [0] * 6
+    for i, c in enumerate(clips):
+        y = O.pcm16_to_float(c)
+        want = O.extract_audio_features(y, 22050, op)
+        assert np.abs(res["pooled"][i][:120] - want[:120]).max() <= 1e-4, i
+        S = O.stft_power(y, op)
+        tun, dbg = O.estimate_tuning(S, op)
+        if res["tuning"][i] == dbg["index"]:
+            assert np.abs(res["pooled"][i][120:] - want[120:]).max() <= 1e-4, i
+        else:  # the histogram arg-max is a near-tie in most clips; a flip must stay a one-bin event
+            assert abs(int(res["tuning"][i]) - dbg["index"]) <= 1, (i, res["tuning"][i], dbg["index"])
+        T = op.n_frames(len(c))
+        ref = O.frame_level_stack(y, op)
+        assert (np.abs(res["frames"][i][:, :T] - ref) <= _frame_tol(ref)).all()
+        assert (res["frames"][i][:, T:] == 0).all()
+
+
+def test_sub_batched_launch_equals_single_launch(monkeypatch):
+    """Huge batches (BASELINE configs[3]: 100k clips) run as several sub-batches that reuse one workspace."""
+    clips = [synth_clip(i % 7, n=16000 + 800 * (i % 5)) for i in range(40)]
+    ref = rsd_amd.FeatureExtractor(B512, 0).extract_batch(clips, frames=True)
+    monkeypatch.setenv("DYSF_WS_MB", "1")  # 1 MiB of per-clip workspace -> a handful of clips per sub-batch
+    small = rsd_amd.FeatureExtractor(B512, 0)
+    got = small.extract_batch(clips, frames=True)
+    small.close()
+    for k in ("pooled", "frames", "status"):
+        assert np.array_equal(ref[k], got[k]), k
+
+
+def test_cnn_head_fp16_agreement(ex512):
+    """configs[4] asks for the CNN in fp16: report agreement with the fp32 head (random weights, so no oracle)."""
+    from rsd_amd.classifier import CNNHead
+    clips = np.stack([synth_clip(i) for i in range(16)])
+    pcm = torch.from_numpy(clips.reshape(-1)).cuda()
+    off = torch.arange(0, 17, dtype=torch.int64, device="cuda") * 48000
+    fr = ex512.extract_batch_device(pcm, off, 48000, pooled=False, frames=True)["frames"]
+    cnn = CNNHead().cuda()
+    with torch.no_grad():
+        l32 = cnn(fr)
+        l16 = cnn.half()(fr.half()).float()
+    agree = float((l32.argmax(1) == l16.argmax(1)).float().mean())
+    assert torch.isfinite(l16).all() and agree >= 0.8, agree
