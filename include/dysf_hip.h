@@ -124,6 +124,11 @@ int32_t dysf_debug_stft_power_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_
 int32_t dysf_debug_logmel_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, int64_t n_samples,
                               float* d_logmel, void* stream);
 
+/* Measurement hook (bench.py): when enabled, every dysf_extract_batch_dev records HIP events on the launch
+ * stream around its kernels; a later call with ms3 != NULL waits for them and returns the durations in ms of
+ * {STFT+mel kernel, MFCC kernel, chroma kernel} of the most recent launch.                                   */
+int32_t dysf_debug_timing(DysfHandle* h, int32_t enable, float* ms3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ struct DysfHandle {
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
+  bool timing = false;           // dysf_debug_timing: HIP events around each kernel of the last sub-batch
+  hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   DevBuf st_pcm, st_off, st_pooled, st_frames, st_status, st_tuning;
   DevBuf d_mel_sched;
   int mel_slots = 0;
@@ -127,6 +130,7 @@ void dysf_destroy(DysfHandle* h) {
     h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release();
+    for (int i = 0; i < 4; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   }
   delete h;
 }
@@ -158,6 +162,23 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
   return n;
 }
 
+
+#ifdef DYSF_STAMP
+// diagnostic build only (not declared in dysf_hip.h): per-phase cycle sums of thread 0 of every workgroup
+int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out16, int32_t reset) {
+  if (!h || h->device < 0) return DYSF_E_INVALID;
+  const size_t bytes = (size_t)8192 * 16 * 8;  // one private row of 16 slots per workgroup (index mod 8192)
+  if (!h->dbg_stamps) { if (hipMalloc((void**)&h->dbg_stamps, bytes) != hipSuccess) return DYSF_E_HIP; (void)hipMemset(h->dbg_stamps, 0, bytes); }
+  (void)hipDeviceSynchronize();
+  if (out16) {
+    std::vector<uint64_t> all((size_t)8192 * 16);
+    (void)hipMemcpy(all.data(), h->dbg_stamps, bytes, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int w = 0; w < 8192; ++w) out16[i] += all[(size_t)w * 16 + i]; }
+  }
+  if (reset) (void)hipMemset(h->dbg_stamps, 0, bytes);
+  return 0;
+}
+#endif
 
 }  // extern "C"
 
@@ -232,7 +253,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   std::memset(&a, 0, sizeof(a));
   a.pcm = d_pcm; a.hop = p.hop; a.sr = p.sr; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
   a.pooled_dim = dysf_pooled_dim(h); a.frame_stride = frame_stride;
-  a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel;
+  a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel; a.dbg_stamps = h->dbg_stamps;
   a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
   a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.mel_pack = h->d_mel_pack;
@@ -256,6 +277,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.mel_sched = (const int*)h->d_mel_sched.p;
   a.mel_slots = h->mel_slots;
   a.tiles_per_wg = 4;
+  if (const char* e = std::getenv("DYSF_TILES")) { if (std::atoi(e) > 0) a.tiles_per_wg = std::atoi(e); }
   a.tpad = (int)((t_max + 15) & ~(int64_t)15);
   a.ws_logmel_stride = (int64_t)p.n_mels * a.tpad;
   a.peak_tile_cap = p.chroma ? fpi_a * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
@@ -310,12 +332,16 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.ws_peak_cnt = (int*)h->ws_small.p + 2 * sub;
     HIPCHK(hipMemsetAsync(h->ws_small.p, 0, (size_t)sub * 12, stream));
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
+    if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
     HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
+    if (h->timing) HIPCHK(hipEventRecord(h->tev[1], stream));
     HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
+    if (h->timing) HIPCHK(hipEventRecord(h->tev[2], stream));
     if (p.chroma) {
       a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
       HIPCHK(launch_chroma(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
     }
+    if (h->timing) HIPCHK(hipEventRecord(h->tev[3], stream));
   }
   return 0;
 }
@@ -366,6 +392,19 @@ int32_t dysf_extract_batch(DysfHandle* h, const void* pcm, int32_t pcm_type, con
   if (frames) HIPCHK(hipMemcpy(frames, h->st_frames.p, (size_t)n_clips * fr * frame_stride * 4, hipMemcpyDeviceToHost));
   if (status) HIPCHK(hipMemcpy(status, h->st_status.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
   if (tuning) HIPCHK(hipMemcpy(tuning, h->st_tuning.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int32_t dysf_debug_timing(DysfHandle* h, int32_t enable, float* ms3) {
+  if (!h || h->device < 0) return fail(DYSF_E_INVALID, "null handle or no device");
+  HIPCHK(hipSetDevice(h->device));
+  if (enable && !h->tev[0])
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&h->tev[i]));
+  if (ms3 && h->timing && h->tev[0]) {
+    HIPCHK(hipEventSynchronize(h->tev[3]));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&ms3[i], h->tev[i], h->tev[i + 1]));
+  }
+  h->timing = enable != 0;
   return 0;
 }
 

@@ -21,6 +21,7 @@ struct KArgs {
   int* tuning;
   float* dbg_S;       // [T][n_bins] of clip 0 (single-clip debug launches only)
   float* dbg_logmel;  // [T][n_mels]
+  unsigned long long* dbg_stamps;  // [16] cycle sums, DYSF_STAMP diagnostic builds only
   // parameters
   int sr, hop, kpad, n_mels, n_mfcc;
   float top_db, amin, db_amin;

@@ -385,8 +385,18 @@ __device__ __forceinline__ float dec_ordered(unsigned u) {
 }
 
 #ifdef DYSF_STAMP
-#define STAMP(i) do {} while (0)
+// diagnostic build only (make stamp): lane 0 of wave 0 adds the cycles since its previous stamp to slot i
+#define STAMP_INIT unsigned long long stamp_last = __builtin_readcyclecounter()
+#define STAMP(i)                                                              \
+  do {                                                                        \
+    if (threadIdx.x == 0 && a.dbg_stamps) {                                   \
+      const unsigned long long now_ = __builtin_readcyclecounter();           \
+      a.dbg_stamps[(size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] += now_ - stamp_last; \
+      stamp_last = now_;                                                      \
+    }                                                                         \
+  } while (0)
 #else
+#define STAMP_INIT do {} while (0)
 #define STAMP(i) do {} while (0)
 #endif
 
@@ -407,6 +417,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane / L, ls = lane % L;
+  STAMP_INIT;
   const int clip = blockIdx.y;
   const long long off = a.offsets[clip];
   const long long n = a.offsets[clip + 1] - off;
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
   bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
   __syncthreads();
+  STAMP(0);  // setup: tables, schedule, first tile staged
   for (int j = 0; j < ntiles; ++j) {
     const int f0 = (ti0 + j) * FPI;
     const int cur_shift = shift;
@@ -458,7 +470,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
       wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
       if (a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
     }
+    STAMP(1);  // prefetch issue + FFT
     __syncthreads();  // S tile complete; every wave is done reading the PCM tile
+    STAMP(2);  // barrier
     if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
     if (a.dbg_S) {
       for (int i = tid; i < FPI * (NC + 1); i += NT) {
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
     }
     // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16], following this wave's
     // slice of the host-built schedule (row blocks with long bands are split along K over several waves)
+    STAMP(3);  // commit
     MelSeg fin;
     fin.kind = 0;
     const int nseg = wsched[kMelMaxSeg * 8];
@@ -500,12 +515,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
         mel_epilogue<FPI>(acc, g, a, lm, f0, T, lane, lmax);
       }
     }
+    STAMP(4);  // mel segments
     __syncthreads();  // PCM tile of the next iteration is in place; S regions are free again
+    STAMP(5);  // barrier
     if (fin.kind == 2) {  // finish the split row block: add the other waves' partial sums, then log + store
       for (int pidx = 0; pidx < fin.nparts; ++pidx) pend += *(const f32x4*)(slots + ((fin.slot + pidx) * 64 + lane) * 4);
       mel_epilogue<FPI>(pend, fin, a, lm, f0, T, lane, lmax);
     }
   }
+  STAMP(6);  // finisher epilogues
   // clip-global maximum of the log-mel (for the top_db clamp) and the non-finite flag
   lmax = wave_max(lmax);
   if (lane == 0) misc[wave] = lmax;
@@ -535,6 +553,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int CSTR = COLS + 1;          // LDS row stride of the MFCC chunk
   constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
   extern __shared__ __align__(16) float lds[];
+  STAMP_INIT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
@@ -571,8 +590,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   for (int i = 0; i < RPW; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
+  STAMP(8);  // setup
   for (int t0 = 0; t0 < T; t0 += CH) {
     __syncthreads();
+    STAMP(9);  // barrier
     {
       int t = t0 - 8 + wave * 16 + (lane & 15);
       t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
@@ -607,7 +628,9 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
           for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
             chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
     }
+    STAMP(10);  // DCT
     __syncthreads();
+    STAMP(11);  // barrier
 #pragma unroll
     for (int sub = 0; sub < (CH + 63) / 64; ++sub) {
       const int t = t0 + sub * 64 + lane;
@@ -649,6 +672,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       }
     }
   }
+  STAMP(12);  // last chunk's deltas (the others are inside slot 9)
   if (frow && a.frame_stride > T) {  // zero-fill the padding columns
     const int padc = (int)(a.frame_stride - T);
     for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
@@ -683,6 +707,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       wave_lds_sync();
     }
   }
+  STAMP(13);  // final reduction
 }
 
 // =============================================================================================

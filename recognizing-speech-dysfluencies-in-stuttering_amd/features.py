@@ -117,6 +117,13 @@ class FeatureExtractor:
             ptr("pooled"), ptr("frames"), fs, ptr("status"), ptr("tuning"), stream))
         return res
 
+    def kernel_timing(self, enable: bool = True):
+        """Measurement hook: returns {'stft_mel', 'mfcc', 'chroma'} durations in ms of the most recent device-resident
+        launch (HIP events recorded on the launch stream), then keeps event recording on/off as requested."""
+        ms = (ctypes.c_float * 3)()
+        _lib.check(_lib.lib().dysf_debug_timing(self._h, 1 if enable else 0, ms))
+        return {"stft_mel": ms[0], "mfcc": ms[1], "chroma": ms[2]}
+
     # ---------------------------------------------------------------- kernel-level test hooks
     def _debug_dev(self, fn, y: np.ndarray, cols: int) -> np.ndarray:
         import torch
