@@ -416,7 +416,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   int* imisc = (int*)misc;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane / L, ls = lane % L;
+  const int q = lane / L;
+  // odd frames of a wave take their FFT lane roles rotated by L/2: the two frames that share a 32-lane LDS access
+  // group then read the PCM tile 16 banks apart (frames are a multiple of 32 banks apart whenever hop % 32 == 0)
+  const int ls = (FPW == 4) ? ((lane + ((q & 1) ? L / 2 : 0)) % L) : lane % L;
   STAMP_INIT;
   const int clip = blockIdx.y;
   const long long off = a.offsets[clip];
@@ -727,7 +730,10 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   float* misc = lds + a.lds_misc;  // [0] scratch (int), [16..115] histogram (int), [128..] chroma partial tiles
   int* imisc = (int*)misc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane / L, ls = lane % L;
+  const int q = lane / L;
+  // odd frames of a wave take their FFT lane roles rotated by L/2: the two frames that share a 32-lane LDS access
+  // group then read the PCM tile 16 banks apart (frames are a multiple of 32 banks apart whenever hop % 32 == 0)
+  const int ls = (FPW == 4) ? ((lane + ((q & 1) ? L / 2 : 0)) % L) : lane % L;
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
   const long long off = a.offsets[clip];

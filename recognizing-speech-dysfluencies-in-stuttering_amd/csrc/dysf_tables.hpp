@@ -121,9 +121,13 @@ inline void fill_fft_tables(HostTables& t) {
   }
 }
 
-inline int round_kpad(int n_bins) {  // smallest >= n_bins with kpad % 32 == 2 (conflict-free MFMA B reads)
+// Row stride of the power-spectrum rows in LDS.  The MFMA B reads (16 frames x 2 K-values per 32-lane group) are
+// conflict-free for kpad % 32 == 2 and, with 4 rows per wave region (region stride % 32 == 8), also for 18; 18
+// additionally puts the rows of the two frames that share a 32-lane group 18 banks apart for the row stores.
+inline int round_kpad(int n_bins, int frames_per_wave) {
+  const int want = frames_per_wave == 4 ? 18 : 2;
   int k = n_bins;
-  while (k % 32 != 2) ++k;
+  while (k % 32 != want) ++k;
   return k;
 }
 
@@ -138,7 +142,6 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   if (!(p.amin > 0.f)) { *err = "amin must be positive"; return false; }
   const int n_fft = p.n_fft, sr = p.sr;
   t.n_bins = n_fft / 2 + 1;
-  t.kpad = round_kpad(t.n_bins);
   t.mpad = (p.n_mels + 15) / 16 * 16;
   t.cpad = (p.n_mfcc + 15) / 16 * 16;
   switch (n_fft) {
@@ -147,6 +150,7 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
     case 1024: fill_fft_tables<512>(t); break;
     default: fill_fft_tables<1024>(t); break;
   }
+  t.kpad = round_kpad(t.n_bins, t.FPW);
   // periodic Hann (scipy.signal.get_window('hann', n, fftbins=True))
   t.window.resize(n_fft);
   for (int n = 0; n < n_fft; ++n) t.window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)n_fft));
