@@ -305,3 +305,21 @@ def test_cnn_head_fp16_agreement(ex512):
         l16 = cnn.half()(fr.half()).float()
     agree = float((l32.argmax(1) == l16.argmax(1)).float().mean())
     assert torch.isfinite(l16).all() and agree >= 0.8, agree
+
+
+def test_streaming_ingest_matches_resident_path(ex149, golden_dir, tmp_path):
+    """WAV files -> pinned double-buffered H2D -> kernels -> pooled rows; same numbers as the
+    resident path, unreadable files become zero rows."""
+    from rsd_amd.ingest import StreamingExtractor, pack_wavs
+    d = os.path.join(golden_dir, "ref_pairs")
+    paths = [os.path.join(d, f"{i:02d}.wav") for i in range(13)] + [str(tmp_path / "missing.wav")]
+    flat, offsets, ok = pack_wavs(paths, 16000)
+    assert ok == [True] * 13 + [False]
+    got = StreamingExtractor(ex149, chunk_clips=4).run(flat, offsets)
+    clips = [flat[offsets[i]:offsets[i + 1]] for i in range(14)]
+    want = ex149.extract_batch(clips)
+    assert np.array_equal(got["pooled"], want["pooled"]) and np.array_equal(got["status"], want["status"])
+    assert got["status"][-1] == 3 and (got["pooled"][-1] == 0).all()
+    for i in range(13):
+        gold = np.load(os.path.join(d, f"{i:02d}.npy"))
+        assert np.abs(got["pooled"][i] - gold[:144]).max() <= 1e-4
