@@ -124,6 +124,10 @@ int32_t dysf_debug_stft_power_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_
 int32_t dysf_debug_logmel_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, int64_t n_samples,
                               float* d_logmel, void* stream);
 
+/* Test hook (chroma presets): the piptrack peak list (magnitude, histogram bin) of clip 0 of the most recent launch,
+ * in append order.  Returns the number of peaks found (which may exceed cap).                                   */
+int64_t dysf_debug_peaks(DysfHandle* h, float* mag, int32_t* bin, int64_t cap);
+
 /* Measurement hook (bench.py): when enabled, every dysf_extract_batch_dev records HIP events on the launch
  * stream around its kernels; a later call with ms3 != NULL waits for them and returns the durations in ms of
  * {STFT+mel kernel, MFCC kernel, chroma kernel} of the most recent launch.                                   */

@@ -16,7 +16,7 @@ SYMBOLS = (
     "dysf_abi_version", "dysf_last_error", "dysf_params_preset", "dysf_create", "dysf_destroy",
     "dysf_pooled_dim", "dysf_frame_rows", "dysf_num_frames", "dysf_debug_table",
     "dysf_extract_batch_dev", "dysf_extract_batch", "dysf_debug_stft_power_dev", "dysf_debug_logmel_dev",
-    "dysf_debug_timing",
+    "dysf_debug_timing", "dysf_debug_peaks",
 )
 
 
@@ -70,6 +70,8 @@ def lib():
     L.dysf_debug_stft_power_dev.argtypes = [vp, vp, i32, i64, vp, vp]
     L.dysf_debug_logmel_dev.argtypes = [vp, vp, i32, i64, vp, vp]
     L.dysf_debug_timing.argtypes = [vp, i32, vp]
+    L.dysf_debug_peaks.argtypes = [vp, vp, vp, i64]
+    L.dysf_debug_peaks.restype = i64
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

@@ -55,6 +55,7 @@ struct DysfHandle {
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
+  int64_t last_sub = 0, last_peak_stride = 0;  // geometry of the most recent launch (dysf_debug_peaks)
   bool timing = false;           // dysf_debug_timing: HIP events around each kernel of the last sub-batch
   hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
@@ -319,6 +320,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     std::fprintf(stderr, "[dysf] stft: %d thr, grid %dx%lld, lds %zu B | mfcc: lds %zu B | chroma: lds %zu B | sub-batch %lld clips, slots %d\n",
                  nt_a, groups, (long long)sub, lds_a, lds_b, p.chroma ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
 
+  h->last_sub = sub; h->last_peak_stride = a.ws_peak_stride;
   for (int64_t c0 = 0; c0 < n_clips; c0 += sub) {
     const int nc = (int)std::min<int64_t>(sub, n_clips - c0);
     a.offsets = (const long long*)d_offsets + c0;
@@ -393,6 +395,18 @@ int32_t dysf_extract_batch(DysfHandle* h, const void* pcm, int32_t pcm_type, con
   if (status) HIPCHK(hipMemcpy(status, h->st_status.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
   if (tuning) HIPCHK(hipMemcpy(tuning, h->st_tuning.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+int64_t dysf_debug_peaks(DysfHandle* h, float* mag, int32_t* bin, int64_t cap) {
+  if (!h || h->device < 0 || !h->ws_peak_mag.p || !h->ws_small.p) return fail(DYSF_E_INVALID, "no chroma launch to inspect");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  int32_t cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, (const int32_t*)h->ws_small.p + 2 * h->last_sub, 4, hipMemcpyDeviceToHost));
+  const int64_t n = std::min<int64_t>(std::min<int64_t>(cnt, cap), h->last_peak_stride);
+  if (n > 0 && mag) HIPCHK(hipMemcpy(mag, h->ws_peak_mag.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (n > 0 && bin) HIPCHK(hipMemcpy(bin, h->ws_peak_bin.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return cnt;
 }
 
 int32_t dysf_debug_timing(DysfHandle* h, int32_t enable, float* ms3) {

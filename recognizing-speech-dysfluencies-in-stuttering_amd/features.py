@@ -144,6 +144,14 @@ class FeatureExtractor:
         """[T, n_mels] un-clamped log-mel spectrogram of one clip (device kernel, debug hook)."""
         return self._debug_dev(_lib.lib().dysf_debug_logmel_dev, y, self.params.n_mels)
 
+    def peaks(self, y: np.ndarray):
+        """(mag, bin) arrays of the piptrack peaks the tuning estimate saw for one clip (chroma presets, debug hook)."""
+        self.extract_batch([y])
+        cap = 1 << 16
+        mag, b = np.zeros(cap, np.float32), np.zeros(cap, np.int32)
+        n = _lib.check(_lib.lib().dysf_debug_peaks(self._h, _vp(mag), _vp(b), cap))
+        return mag[:n], b[:n]
+
     def table(self, which: int, arg: int = 0) -> np.ndarray:
         p = self.params
         size = {0: p.n_fft, 1: p.n_mels * p.n_bins, 2: p.n_mfcc * p.n_mels, 3: 12 * p.n_bins}[which]
