@@ -133,6 +133,25 @@ int64_t dysf_debug_peaks(DysfHandle* h, float* mag, int32_t* bin, int64_t cap);
  * {STFT+mel kernel, MFCC kernel, chroma kernel} of the most recent launch.                                   */
 int32_t dysf_debug_timing(DysfHandle* h, int32_t enable, float* ms3);
 
+/*
+ * RandomForest inference: replaces scaler.transform + rf.predict / rf.predict_proba of the
+ * single-clip predictor, main1.py:987-989 (model of pipeline1.py:496).  The forest is given as flat node arrays
+ * (sklearn tree_.feature / threshold / children_left / children_right with tree-local child indices rebased to the
+ * flat array, leaf rows of tree_.value normalised to class fractions); children must follow their parent.
+ *   d_x      [n, n_features] float32 UNscaled feature rows (device); scaling by (mean, scale) is done in-kernel
+ *            with StandardScaler's float32 rounding steps
+ *   d_proba  [n, n_classes] float64 or NULL;  d_pred [n] int32 (first arg-max) or NULL
+ */
+typedef struct DysfForest DysfForest;
+const char* dysf_forest_last_error(void);
+int32_t dysf_forest_create(int32_t device, int32_t n_features, int32_t n_classes, int32_t n_trees, int64_t n_nodes,
+                           const int32_t* feature, const double* threshold, const int32_t* left, const int32_t* right,
+                           const double* value, const int32_t* root, const double* mean, const double* scale,
+                           DysfForest** out);
+void    dysf_forest_destroy(DysfForest* f);
+int32_t dysf_forest_predict_dev(DysfForest* f, const float* d_x, int32_t n, double* d_proba, int32_t* d_pred,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ SYMBOLS = (
     "dysf_pooled_dim", "dysf_frame_rows", "dysf_num_frames", "dysf_debug_table",
     "dysf_extract_batch_dev", "dysf_extract_batch", "dysf_debug_stft_power_dev", "dysf_debug_logmel_dev",
     "dysf_debug_timing", "dysf_debug_peaks",
+    "dysf_forest_last_error", "dysf_forest_create", "dysf_forest_destroy", "dysf_forest_predict_dev",
 )
 
 
@@ -72,6 +73,11 @@ def lib():
     L.dysf_debug_timing.argtypes = [vp, i32, vp]
     L.dysf_debug_peaks.argtypes = [vp, vp, vp, i64]
     L.dysf_debug_peaks.restype = i64
+    L.dysf_forest_last_error.restype = ctypes.c_char_p
+    L.dysf_forest_create.argtypes = [i32, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dysf_forest_destroy.argtypes = [vp]
+    L.dysf_forest_destroy.restype = None
+    L.dysf_forest_predict_dev.argtypes = [vp, vp, i32, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

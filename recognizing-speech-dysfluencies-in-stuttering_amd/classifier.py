@@ -57,6 +57,72 @@ class MLPHead(nn.Module):
         return [self.classes[int(i)] for i in idx]
 
 
+class RandomForestHead:
+    """scaler.transform + RandomForestClassifier.predict / predict_proba (main1.py:987-989, model of pipeline1.py:496)
+    on the GPU: a HIP tree-walk kernel behind the C ABI (``dysf_forest_*``).  Built from flat node arrays exported
+    from a fitted scikit-learn forest (see tests/golden/make_golden.py: forest_fixture)."""
+
+    def __init__(self, feature, threshold, left, right, value, root, mean, scale, classes=None, device: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.device = device
+        self.n_classes = int(np.asarray(value).shape[1])
+        self.n_features_in_ = int(np.asarray(mean).shape[0])
+        self.classes = None if classes is None else [str(c) for c in classes]
+        arrs = [np.ascontiguousarray(feature, np.int32), np.ascontiguousarray(threshold, np.float64),
+                np.ascontiguousarray(left, np.int32), np.ascontiguousarray(right, np.int32),
+                np.ascontiguousarray(value, np.float64), np.ascontiguousarray(root, np.int32),
+                np.ascontiguousarray(mean, np.float64), np.ascontiguousarray(scale, np.float64)]
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.dysf_forest_create(device, self.n_features_in_, self.n_classes, len(arrs[5]), len(arrs[0]),
+                                  *[vp(a) for a in arrs], ctypes.byref(self._h))
+        if rc != 0:
+            raise _lib.DysfError(f"dysf_forest_create failed ({rc}): {L.dysf_forest_last_error().decode()}")
+
+    @classmethod
+    def from_npz(cls, path: str, classes=None, device: int = 0) -> "RandomForestHead":
+        z = np.load(path, allow_pickle=False)
+        return cls(z["feature"], z["threshold"], z["left"], z["right"], z["value"], z["root"], z["mean"], z["scale"],
+                   classes=classes, device=device)
+
+    def _run(self, x: torch.Tensor):
+        import ctypes
+        if x.shape[-1] != self.n_features_in_:
+            raise ValueError(f"Feature mismatch! Expected {self.n_features_in_}, got {x.shape[-1]}.")
+        x = x.to(torch.float32).contiguous()
+        assert x.is_cuda
+        n = x.shape[0]
+        proba = torch.empty((n, self.n_classes), dtype=torch.float64, device=x.device)
+        pred = torch.empty(n, dtype=torch.int32, device=x.device)
+        L = self._lib.lib()
+        rc = L.dysf_forest_predict_dev(self._h, ctypes.c_void_p(x.data_ptr()), n, ctypes.c_void_p(proba.data_ptr()),
+                                       ctypes.c_void_p(pred.data_ptr()),
+                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.DysfError(f"dysf_forest_predict_dev failed ({rc}): {L.dysf_forest_last_error().decode()}")
+        return proba, pred
+
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x)[0]
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x)[1].to(torch.int64)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lib().dysf_forest_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CNNHead(nn.Module):
     """Conv2d(1->32,3x3,p1) ReLU MaxPool2 Conv2d(32->64,3x3,p1) ReLU global-avg-pool Linear(64->3) on
     [B, 1, 3*n_mfcc, T] frame-level features; random weights from ``torch.manual_seed(seed)``."""

@@ -18,6 +18,7 @@ Outputs (all under tests/golden/):
   ref_pairs/NN.wav, NN.npy the shortest N real pairs; travels to the GPU box
   classifier_after.npz     StandardScaler + MLP(128,64) re-fit exactly as pipeline1.py:462-531 does,
                            with the 905x149 feature matrix and expected predict / predict_proba
+  forest_after.npz         the RandomForest(200) of pipeline1.py:496 as flat node arrays + expected outputs
 """
 import csv
 import glob
@@ -148,7 +149,57 @@ def classifier_fixture():
         evidence=json.dumps(evidence))
 
 
+def forest_fixture():
+    """RandomForestClassifier(n_estimators=200, random_state=42) re-fit exactly as pipeline1.py:496, 512-514 does on the
+    cleaned ("after") features; exported as flat node arrays for the GPU traversal kernel (the
+    deployed predictor of main1.py:984-989 is the forest)."""
+    from sklearn.ensemble import RandomForestClassifier
+    from sklearn.metrics import accuracy_score, confusion_matrix, log_loss
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import LabelEncoder, StandardScaler
+
+    files = list_audio_files(os.path.join(REF, "segrigated_samples"))
+    labels = [os.path.basename(os.path.dirname(f)) for f in files]
+    X_after = np.vstack([np.load(os.path.join(REF, "cache_features",
+                                              os.path.basename(f).rsplit(".", 1)[0] + "_clean_feats.npy"))
+                         for f in files])
+    y = LabelEncoder().fit_transform(labels)
+    scaler = StandardScaler().fit(X_after)
+    Xs = scaler.transform(X_after)
+    Xtr, Xte, ytr, yte = train_test_split(Xs, y, test_size=0.2, stratify=y, random_state=42)
+    rf = RandomForestClassifier(n_estimators=200, random_state=42).fit(Xtr, ytr)
+    pred_te, proba_te = rf.predict(Xte), rf.predict_proba(Xte)
+    acc, loss = float(accuracy_score(yte, pred_te) * 100.0), float(log_loss(yte, proba_te))
+    cm = confusion_matrix(yte, pred_te)
+    with open(os.path.join(REF, "output_results", "confusion_after_RandomForest.csv")) as f:
+        ref_cm = np.array([[int(v) for v in row[1:]] for row in list(csv.reader(f))[1:]])
+    evidence = {"accuracy": acc, "log_loss": loss, "confusion_matches_reference": bool((cm == ref_cm).all()),
+                "reference_metrics_summary_after_RandomForest": [65.74585635359117, 0.8522499830310881]}
+    print(json.dumps(evidence, indent=1))
+    feat, thr, left, right, value, root = [], [], [], [], [], []
+    for est in rf.estimators_:
+        t = est.tree_
+        root.append(len(feat))
+        base = len(feat)
+        feat += t.feature.tolist()
+        thr += t.threshold.tolist()
+        left += [c + base if c >= 0 else -1 for c in t.children_left]
+        right += [c + base if c >= 0 else -1 for c in t.children_right]
+        value += t.value[:, 0, :].tolist()  # class fractions as stored (sklearn >= 1.4): what tree.predict_proba returns
+    np.savez_compressed(
+        os.path.join(HERE, "forest_after.npz"),
+        feature=np.array(feat, np.int32), threshold=np.array(thr, np.float64), left=np.array(left, np.int32),
+        right=np.array(right, np.int32), value=np.array(value, np.float64), root=np.array(root, np.int32),
+        mean=scaler.mean_, scale=scaler.scale_,
+        expected_pred=rf.predict(Xs).astype(np.int64), expected_proba=rf.predict_proba(Xs),
+        evidence=json.dumps(evidence))
+
+
 if __name__ == "__main__":
+    if "--forest-only" in sys.argv:
+        forest_fixture()
+        sys.exit(0)
     lengths = validate_all()
     copy_pairs(lengths)
     classifier_fixture()
+    forest_fixture()

@@ -323,3 +323,21 @@ def test_streaming_ingest_matches_resident_path(ex149, golden_dir, tmp_path):
     for i in range(13):
         gold = np.load(os.path.join(d, f"{i:02d}.npy"))
         assert np.abs(got["pooled"][i] - gold[:144]).max() <= 1e-4
+
+
+def test_random_forest_head_matches_sklearn_fixture(golden_dir):
+    """the reference's deployed predictor (RandomForest(200) on scaled features, main1.py:987-989)
+    as a HIP tree-walk kernel.  Fixture = the forest re-fit exactly as pipeline1.py:496 does (its accuracy, log-loss
+    and confusion matrix equal output_results/metrics_summary.csv:5 / confusion_after_RandomForest.csv)."""
+    from rsd_amd.classifier import RandomForestHead
+    z = np.load(os.path.join(golden_dir, "forest_after.npz"))
+    X = np.load(os.path.join(golden_dir, "classifier_after.npz"))["X"]
+    head = RandomForestHead.from_npz(os.path.join(golden_dir, "forest_after.npz"))
+    x = torch.from_numpy(X).cuda()
+    pred = head.predict(x).cpu().numpy()
+    proba = head.predict_proba(x).cpu().numpy()
+    assert np.array_equal(pred, z["expected_pred"])            # arg-max exact on all 905 rows
+    assert np.abs(proba - z["expected_proba"]).max() <= 1e-12   # float64 average of the same leaf fractions
+    with pytest.raises(ValueError):
+        head.predict(torch.zeros(1, 148).cuda())
+    head.close()

@@ -135,3 +135,26 @@ def test_cnn_head_shape_and_seed():
     a, b = CNNHead(), CNNHead()
     assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
     assert a(torch.zeros(2, 120, 301)).shape == (2, 3)
+
+
+def test_forest_fixture_reproduces_reference_metrics(golden_dir):
+    import json
+    z = np.load(os.path.join(golden_dir, "forest_after.npz"))
+    ev = json.loads(str(z["evidence"]))
+    assert ev["confusion_matches_reference"] is True
+    assert abs(ev["accuracy"] - 65.74585635359117) < 1e-9 and abs(ev["log_loss"] - 0.8522499830310881) < 1e-9
+    assert len(z["root"]) == 200 and z["value"].shape[1] == 3 and np.allclose(z["value"].sum(axis=1), 1.0)
+    leaf = z["feature"] < 0
+    assert (z["left"][~leaf] > np.nonzero(~leaf)[0]).all()  # children follow parents: every walk terminates
+    # a pure-NumPy walk of the flat arrays gives the stored expectations (pins the export format on CPU)
+    X = np.load(os.path.join(golden_dir, "classifier_after.npz"))["X"]
+    xs = (((X.astype(np.float64) - z["mean"]).astype(np.float32)).astype(np.float64) / z["scale"]).astype(np.float32)
+    rows = [17, 904]
+    for r in rows:
+        acc = np.zeros(3)
+        for root in z["root"]:
+            node = int(root)
+            while z["feature"][node] >= 0:
+                node = int(z["left"][node] if xs[r, z["feature"][node]] <= z["threshold"][node] else z["right"][node])
+            acc += z["value"][node]
+        assert np.abs(acc / 200 - z["expected_proba"][r]).max() < 1e-12
