@@ -864,8 +864,14 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return e;
+  // the attribute is raised once per kernel (and again only if a later launch needs more): steady-state launches are
+  // pure stream work and can be captured into a hipGraph by the caller
+  static thread_local size_t granted = 0;  // one instance per template instantiation
+  if (lds_bytes > granted) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    granted = lds_bytes;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, s, a);
   return hipGetLastError();
 }
