@@ -866,11 +866,14 @@ template <typename K>
 static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
   // the attribute is raised once per kernel (and again only if a later launch needs more): steady-state launches are
   // pure stream work and can be captured into a hipGraph by the caller
-  static thread_local size_t granted = 0;  // one instance per template instantiation
-  if (lds_bytes > granted) {
+  static size_t granted[64] = {};  // per device; one instance per template instantiation (a handle is single-threaded)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  size_t& have = granted[dev & 63];
+  if (lds_bytes > have) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    granted = lds_bytes;
+    have = lds_bytes;
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, s, a);
   return hipGetLastError();
