@@ -197,8 +197,7 @@ def main():
         k_mfcc = float(np.median([p["mfcc"] for p in per_kernel]))
         k_path = k_stft + k_mfcc  # the feature launch: both kernels back to back on one stream
         achieved = algo_bytes / (k_path * 1e-3) / 1e9
-        tpad = (T + 15) // 16 * 16
-        logmel_bytes = BATCH * params.n_mels * tpad * 4  # the one HBM intermediate (written by one kernel, read by the other)
+        logmel_bytes = BATCH * T * ((params.n_mels + 15) // 16 * 16) * 4  # the one HBM intermediate (written by one kernel, read by the other)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):

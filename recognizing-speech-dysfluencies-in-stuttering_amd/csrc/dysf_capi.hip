@@ -258,7 +258,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
   a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.mel_pack = h->d_mel_pack;
-  a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_steps = t.dct_pack.max_steps;
+  a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_groups = t.dct_groups;
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
 
@@ -279,8 +279,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.mel_slots = h->mel_slots;
   a.tiles_per_wg = 4;
   if (const char* e = std::getenv("DYSF_TILES")) { if (std::atoi(e) > 0) a.tiles_per_wg = std::atoi(e); }
-  a.tpad = (int)((t_max + 15) & ~(int64_t)15);
-  a.ws_logmel_stride = (int64_t)p.n_mels * a.tpad;
+  a.lm_stride = t.mpad;
+  a.ws_logmel_stride = t_max * (int64_t)t.mpad;
   a.peak_tile_cap = p.chroma ? fpi_a * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   a.ws_peak_stride = p.chroma ? t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * t.L + 3) & ~3;
@@ -299,7 +299,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   if (p.chroma && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
 
   // ---- kernel B LDS: frame-0 features, float64 DCT operands, MFCC chunk (the final reduction reuses the last two)
-  const int nd = t.dct_pack.row_blocks * t.dct_pack.max_steps * 64;
+  const int nd = t.dct_pack.row_blocks * t.dct_groups * 256;
   const size_t lds_b = (size_t)(kMfccHead + std::max(2 * nd + t.cpad * 129, 8 * (18 * 65 + 3) + 2 * 8 * 18)) * 4;
 
   // ---- per-clip workspace; very large batches run as several sub-batches that reuse it

@@ -36,14 +36,14 @@ struct KArgs {
   const int* mel_sched;   // per wave kMelSchedStride ints (see below)
   int mel_slots;          // split-K partial tiles kept in LDS
   const double* dct_pack;  // float64 A operands
-  int dct_rb, dct_steps;
+  int dct_rb, dct_groups;  // row blocks of 16 coefficients, K groups of 16 mels
   const float* chroma_pack;
   int chroma_steps;
   int pip_kmin, pip_kmax;
   // per-clip global workspace
-  float* ws_logmel;            // [clip][n_mels][tpad] log-mel (dB, un-clamped)
+  float* ws_logmel;            // [clip][T_max][lm_stride] log-mel (dB, un-clamped), frame-major
   long long ws_logmel_stride;  // floats per clip
-  int tpad;                    // row stride of the log-mel (multiple of 16 floats)
+  int lm_stride;               // floats per log-mel row = n_mels rounded up to 16
   unsigned* ws_clipmax;        // [clip] order-preserving encoding of the clip's log-mel maximum (atomicMax)
   int* ws_flags;               // [clip] 1: non-finite sample seen
   int* ws_peak_cnt;            // [clip] piptrack peaks appended so far

@@ -352,25 +352,29 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   return acc0 + acc1;
 }
 
-// 10*log10 of a finished mel tile -> log-mel [n_mels][tpad] rows of the clip (64-byte row segments), running max
+// 10*log10(x) = log2(x) * 10*log10(2): v_log_f32 plus a two-term constant.  Cells at the amin floor take the
+// host-computed float32(10*log10(amin)) (-100 exactly for 1e-10) so that silent cells are exact.
+__device__ __forceinline__ float power_to_db(float x, const KArgs& a) {
+  const float l2 = __builtin_amdgcn_logf(x);
+  return (x <= a.amin) ? a.db_amin : fmaf(l2, 3.0102999566398120f - 3.01029992103576660f, l2 * 3.01029992103576660f);
+}
+
+// finished mel tile -> four consecutive mels of one frame per lane -> one 16-byte store into the frame-major
+// log-mel workspace [T][lm_stride]; running max over the real mels
 template <int FPI>
 __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const KArgs& a, float* lm, int f0, int T,
                                              int lane, float& lmax) {
   const int f = g.cb * 16 + (lane & 15);
   const int t = f0 + f;
   if (f < FPI && t < T) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = g.rb * 16 + 4 * (lane >> 4) + r;
-      if (m < a.n_mels) {
-        // 10*log10(x) = log2(x) * 10*log10(2), v_log_f32 plus a two-term constant.  Cells at the amin floor take
-        // the host-computed float32(10*log10(amin)) (-100 exactly for 1e-10) so that silent cells are exact.
-        const float l2 = __builtin_amdgcn_logf(acc[r]);
-        const float v = (acc[r] <= a.amin) ? a.db_amin : fmaf(l2, 3.0102999566398120f - 3.01029992103576660f, l2 * 3.01029992103576660f);
-        lm[(size_t)m * a.tpad + t] = v;
-        lmax = fmaxf(lmax, v);
-      }
-    }
+    const int m0 = g.rb * 16 + 4 * (lane >> 4);
+    float4 v;
+    v.x = power_to_db(acc[0], a); v.y = power_to_db(acc[1], a); v.z = power_to_db(acc[2], a); v.w = power_to_db(acc[3], a);
+    *(float4*)(lm + (size_t)t * a.lm_stride + m0) = v;
+    if (m0 + 0 < a.n_mels) lmax = fmaxf(lmax, v.x);
+    if (m0 + 1 < a.n_mels) lmax = fmaxf(lmax, v.y);
+    if (m0 + 2 < a.n_mels) lmax = fmaxf(lmax, v.z);
+    if (m0 + 3 < a.n_mels) lmax = fmaxf(lmax, v.w);
   }
 }
 
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
 }
 
 // =============================================================================================
-// Kernel B: log-mel [n_mels][tpad] -> clamp -> DCT (float64 MFMA) -> deltas -> frame rows + pooled statistics.
+// Kernel B: log-mel [T][lm_stride] -> clamp -> DCT (float64 MFMA) -> deltas -> frame rows + pooled statistics.
 // One workgroup per clip, chunks of CH = 16*NW - 16 output frames; every wave runs one 16-frame column tile of the
 // DCT (8 halo frames each side of the chunk), then owns the MFCC rows c = wave, wave + NW, ... (a lane is a frame).
 // Mean / variance are one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane
@@ -581,11 +585,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   const float clip_max = dec_ordered(a.ws_clipmax[clip]);
   const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
   if (a.dbg_logmel)
-    for (int i = tid; i < T * a.n_mels; i += NT) a.dbg_logmel[i] = lm[(size_t)(i % a.n_mels) * a.tpad + (i / a.n_mels)];
+    for (int i = tid; i < T * a.n_mels; i += NT) a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.lm_stride + (i % a.n_mels)];
 
   float* kshift = lds + kBShift;
   double* dct = (double*)(lds + kBDct);
-  const int nd = a.dct_rb * a.dct_steps * 64;
+  const int nd = a.dct_rb * a.dct_groups * 256;
   float* chunk = lds + kBDct + 2 * nd;
   for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
   float ps[RPW][6];
@@ -600,27 +604,28 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     {
       int t = t0 - 8 + wave * 16 + (lane & 15);
       t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-      const float* lcol = lm + (size_t)(lane >> 4) * a.tpad + t;  // B[k = mel][j = frame]: 16 consecutive frames per mel
-      const double* dp = dct + lane;
-      const int mrem = a.n_mels - (lane >> 4);  // this lane's B row is valid while 4*s < mrem
+      const float* lrow = lm + (size_t)t * a.lm_stride + 4 * (lane >> 4);  // this lane's four mels of every 16-mel group
+      const double* dp = dct + lane * 4;
       f64x4 acc[3];
 #pragma unroll
       for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
-      for (int s = 0; s < a.dct_steps; s += 4) {  // dct_steps is a multiple of 4 (n_mels padded to 16)
-        float bf[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bf[u] = (4 * (s + u) < mrem) ? lcol[(size_t)(4 * (s + u)) * a.tpad] : floor_db;
+      for (int g = 0; g < a.dct_groups; ++g) {
+        const float4 b4 = *(const float4*)(lrow + 16 * g);  // 16 frames x 64 bytes per wave load
+        const int m0 = 16 * g + 4 * (lane >> 4);
+        double bv[4];
+        bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
+        bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
+        bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
+        bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
           if (rb < a.dct_rb) {
-            double av[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = dp[((size_t)rb * a.dct_steps + s + u) * 64];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double bv = (4 * (s + u) < mrem) ? (double)fmaxf(bf[u], floor_db) : 0.0;
-              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc[rb], 0, 0, 0);
-            }
+            const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
+            const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, bv[3], acc[rb], 0, 0, 0);
           }
         }
       }

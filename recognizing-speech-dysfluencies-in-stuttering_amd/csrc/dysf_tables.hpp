@@ -65,7 +65,8 @@ struct HostTables {
   std::vector<float> dct;        // [n_mfcc][n_mels]
   std::vector<float> chroma;     // [100][12][n_bins]   (only when p.chroma)
   MfmaPack mel_pack, dct_pack;
-  std::vector<double> dct_pack64;  // dct_pack layout, exact float64 coefficients (v_mfma_f64_16x16x4_f64)
+  std::vector<double> dct_pack64;  // exact float64 coefficients, K-grouped layout (see build_tables)
+  int dct_groups = 0;               // groups of 16 mels = mpad / 16
   std::vector<float> chroma_pack;  // [100][chroma_steps*64]
   int chroma_steps = 0;
   int pip_kmin = 0, pip_kmax = 0;  // piptrack bins with 150 <= f < min(4000, sr/2)
@@ -195,18 +196,23 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
     t.dct_pack = pack_rows(t.dct, p.n_mfcc, p.n_mels, false);
     // the kernel runs the DCT on the float64 MFMA: identical silent / clamped frames would otherwise repeat
     // one float32 rounding error in every frame and bias the pooled means by ~1e-4
-    const int steps = t.dct_pack.max_steps;
-    t.dct_pack64.assign((size_t)t.dct_pack.row_blocks * steps * 64, 0.0);
+    // K is walked in groups of 16 mels; within a group lane (i = l & 15, k4 = l >> 4) owns the four consecutive
+    // mels 16g + 4*k4 + s (s = MFMA step), so its B operand is ONE 16-byte load of the frame-major log-mel row
+    // and its A operands are four consecutive doubles of this pack: [row block][group][lane][s]
+    const int groups = t.mpad / 16;
+    t.dct_groups = groups;
+    t.dct_pack64.assign((size_t)t.dct_pack.row_blocks * groups * 64 * 4, 0.0);
     for (int rb = 0; rb < t.dct_pack.row_blocks; ++rb)
-      for (int s = 0; s < steps; ++s)
-        for (int l = 0; l < 64; ++l) {
-          const int c = rb * 16 + (l & 15), m = 4 * s + (l >> 4);
-          if (c < p.n_mfcc && m < p.n_mels) {
-            double d = std::cos(M_PI * (double)c * (2.0 * m + 1.0) / (2.0 * M)) * std::sqrt(2.0 / M);
-            if (c == 0) d *= std::sqrt(0.5);
-            t.dct_pack64[((size_t)rb * steps + s) * 64 + l] = d;
+      for (int g = 0; g < groups; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int s = 0; s < 4; ++s) {
+            const int c = rb * 16 + (l & 15), m = 16 * g + 4 * (l >> 4) + s;
+            if (c < p.n_mfcc && m < p.n_mels) {
+              double d = std::cos(M_PI * (double)c * (2.0 * m + 1.0) / (2.0 * M)) * std::sqrt(2.0 / M);
+              if (c == 0) d *= std::sqrt(0.5);
+              t.dct_pack64[(((size_t)rb * groups + g) * 64 + l) * 4 + s] = d;
+            }
           }
-        }
   }
   // piptrack frequency mask
   {
