@@ -419,7 +419,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   float* misc = lds + a.lds_misc;   // [0..15] wave max, [16] peak count (int), then schedule, slots, peak stage
   int* imisc = (int*)misc;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave bases stay in SGPRs
   const int q = lane / L;
   // odd frames of a wave take their FFT lane roles rotated by L/2: the two frames that share a 32-lane LDS access
   // group then read the PCM tile 16 banks apart (frames are a multiple of 32 banks apart whenever hop % 32 == 0)
@@ -505,12 +506,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
     STAMP(3);  // commit
     MelSeg fin;
     fin.kind = 0;
-    const int nseg = wsched[kMelMaxSeg * 8];
+    const int nseg = __builtin_amdgcn_readfirstlane(wsched[kMelMaxSeg * 8]);
     for (int i = 0; i < nseg; ++i) {
       MelSeg g;
       {
         const int4 lo = *(const int4*)(wsched + i * 8), hi = *(const int4*)(wsched + 4 + i * 8);
-        g.rb = lo.x; g.cb = lo.y; g.kbeg = lo.z; g.nsteps = lo.w; g.poff = hi.x; g.kind = hi.y; g.slot = hi.z; g.nparts = hi.w;
+        // the schedule is per wave: make it scalar so the segment loop and its addressing run on the SALU
+        g.rb = __builtin_amdgcn_readfirstlane(lo.x); g.cb = __builtin_amdgcn_readfirstlane(lo.y);
+        g.kbeg = __builtin_amdgcn_readfirstlane(lo.z); g.nsteps = __builtin_amdgcn_readfirstlane(lo.w);
+        g.poff = __builtin_amdgcn_readfirstlane(hi.x); g.kind = __builtin_amdgcn_readfirstlane(hi.y);
+        g.slot = __builtin_amdgcn_readfirstlane(hi.z); g.nparts = __builtin_amdgcn_readfirstlane(hi.w);
       }
       const f32x4 acc = mel_segment<NC, FPW, FPI>(regions, a, a.mel_pack, g, lane);
       if (g.kind == 1) {
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
 constexpr int kBShift = 0;     // float[48][3]: frame-0 features
 constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-byte aligned)
 
-template <int NT>
+template <int NT, int NG>
 __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   constexpr int COLS = 16 * NW;
@@ -561,7 +566,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
   extern __shared__ __align__(16) float lds[];
   STAMP_INIT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row bases and store addresses stay in SGPRs
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
   const long long off = a.offsets[clip];
@@ -597,38 +603,52 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   for (int i = 0; i < RPW; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
+  // The log-mel rows of a chunk are fetched one chunk ahead: the loads of chunk i+1 fly during the delta pass of chunk i
+  // (NG = 16-mel groups held in registers; rows past the clip clamp to the last frame, so the extra fetch is harmless).
+  float4 pf[NG];
+  auto fetch = [&](int t0n) {
+    int t = t0n - 8 + wave * 16 + (lane & 15);
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const float* lrow = lm + (size_t)t * a.lm_stride + 4 * (lane >> 4);  // this lane's four mels of every 16-mel group
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g < a.dct_groups) pf[g] = *(const float4*)(lrow + 16 * g);  // 16 frames x 64 bytes per wave load
+  };
+  fetch(0);
   STAMP(8);  // setup
   for (int t0 = 0; t0 < T; t0 += CH) {
     __syncthreads();
     STAMP(9);  // barrier
     {
-      int t = t0 - 8 + wave * 16 + (lane & 15);
-      t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-      const float* lrow = lm + (size_t)t * a.lm_stride + 4 * (lane >> 4);  // this lane's four mels of every 16-mel group
       const double* dp = dct + lane * 4;
       f64x4 acc[3];
 #pragma unroll
       for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
-      for (int g = 0; g < a.dct_groups; ++g) {
-        const float4 b4 = *(const float4*)(lrow + 16 * g);  // 16 frames x 64 bytes per wave load
-        const int m0 = 16 * g + 4 * (lane >> 4);
-        double bv[4];
-        bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
-        bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
-        bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
-        bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-          if (rb < a.dct_rb) {
-            const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
-            const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
-            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, bv[3], acc[rb], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) {
+        if (g < a.dct_groups) {
+          const float4 b4 = pf[g];
+          const int m0 = 16 * g + 4 * (lane >> 4);
+          double bv[4];
+          bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
+          bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
+          bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
+          bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) {
+            if (rb < a.dct_rb) {
+              const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
+              const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, bv[3], acc[rb], 0, 0, 0);
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);  // keep one group's operands live at a time (the kernel sits at its VGPR cap)
         }
       }
+      fetch(t0 + CH);
 #pragma unroll
       for (int rb = 0; rb < 3; ++rb)
         if (rb < a.dct_rb)
@@ -734,7 +754,8 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   float* tile = lds + a.lds_pcm;
   float* misc = lds + a.lds_misc;  // [0] scratch (int), [16..115] histogram (int), [128..] chroma partial tiles
   int* imisc = (int*)misc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave bases stay in SGPRs
   const int q = lane / L;
   // odd frames of a wave take their FFT lane roles rotated by L/2: the two frames that share a 32-lane LDS access
   // group then read the PCM tile 16 banks apart (frames are a multiple of 32 banks apart whenever hop % 32 == 0)
@@ -906,7 +927,8 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
   }
 }
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  return launch_one(dysf_mfcc_kernel<512>, grid, 512, lds_bytes, s, a);
+  if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_mfcc_kernel<512, 8>, grid, 512, lds_bytes, s, a);
 }
 hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   switch (n_fft) {
