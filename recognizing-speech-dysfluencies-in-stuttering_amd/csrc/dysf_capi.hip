@@ -50,6 +50,9 @@ struct DysfHandle {
   float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr, *d_mel_pack = nullptr,
         *d_chroma_pack = nullptr;
   double* d_dct_pack = nullptr;
+  float* d_dct_pack32 = nullptr;
+  double* d_dct_rowsum = nullptr;
+  bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   int* d_mel_meta = nullptr;
   // workspace / staging
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
@@ -99,6 +102,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   const char* err = "";
   if (!build_tables(*p, h->t, &err)) { delete h; return fail(DYSF_E_INVALID, err); }
   h->device = device;
+  if (const char* e = std::getenv("DYSF_DCT64")) h->dct64 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DYSF_WS_MB")) { if (std::atoll(e) > 0) h->ws_budget = (size_t)std::atoll(e) << 20; }
   if (device >= 0) {
     int rc = 0;
@@ -114,6 +118,8 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     rc |= upload(&h->d_mel_pack, h->t.mel_pack.data);
     rc |= upload(&h->d_mel_meta, h->t.mel_pack.meta);
     rc |= upload(&h->d_dct_pack, h->t.dct_pack64);
+    rc |= upload(&h->d_dct_pack32, h->t.dct_pack32);
+    rc |= upload(&h->d_dct_rowsum, h->t.dct_rowsum);
     rc |= upload(&h->d_chroma_pack, h->t.chroma_pack);
     if (rc) { dysf_destroy(h); return DYSF_E_HIP; }
   }
@@ -126,7 +132,7 @@ void dysf_destroy(DysfHandle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
-    (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack);
+    (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum);
     (void)hipFree(h->d_chroma_pack);
     h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
@@ -259,6 +265,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.mel_pack = h->d_mel_pack;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_groups = t.dct_groups;
+  a.dct_pack32 = h->dct64 ? nullptr : h->d_dct_pack32; a.dct_rowsum = h->d_dct_rowsum; a.inv_n_mels = 1.0f / (float)p.n_mels;
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
 
@@ -300,7 +307,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
 
   // ---- kernel B LDS: frame-0 features, float64 DCT operands, MFCC chunk (the final reduction reuses the last two)
   const int nd = t.dct_pack.row_blocks * t.dct_groups * 256;
-  const size_t lds_b = (size_t)(kMfccHead + std::max(2 * nd + t.cpad * 129, 8 * (18 * 65 + 3) + 2 * 8 * 18)) * 4;
+  const size_t lds_b = (size_t)(kMfccHead + std::max(2 * nd + t.cpad * kMfccCstr, 8 * (18 * 65 + 3) + 2 * 8 * 18)) * 4;
 
   // ---- per-clip workspace; very large batches run as several sub-batches that reuse it
   const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8;

@@ -36,6 +36,9 @@ struct KArgs {
   const int* mel_sched;   // per wave kMelSchedStride ints (see below)
   int mel_slots;          // split-K partial tiles kept in LDS
   const double* dct_pack;  // float64 A operands
+  const float* dct_pack32;   // float32 A operands of the same layout (null: run the DCT on the float64 MFMA)
+  const double* dct_rowsum;  // [16*dct_rb] float64 sums of the float32 coefficients of every row
+  float inv_n_mels;
   int dct_rb, dct_groups;  // row blocks of 16 coefficients, K groups of 16 mels
   const float* chroma_pack;
   int chroma_steps;
@@ -58,6 +61,7 @@ struct KArgs {
 constexpr int kMelMaxSeg = 4;
 constexpr int kMelSchedStride = 40;  // ints per wave: kMelMaxSeg x {rb, cb, kbeg, nsteps, poff, kind, slot, nparts}, nseg at [32]
 constexpr int kStftMiscBase = 32 + 8 * kMelSchedStride;  // kernel A misc area before the split-K slots
+constexpr int kMfccCstr = 132;                           // kernel B: LDS row stride of the MFCC chunk (128 columns)
 constexpr int kMfccHead = 144;                           // kernel B: frame-0 features ahead of the DCT operands
 
 // kernel A workgroup size: 16 frames per tile up to n_fft 1024, 8 frames at n_fft 2048

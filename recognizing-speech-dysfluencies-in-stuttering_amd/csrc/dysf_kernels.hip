@@ -557,12 +557,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
 constexpr int kBShift = 0;     // float[48][3]: frame-0 features
 constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-byte aligned)
 
-template <int NT, int NG>
+template <int NT, int NG, bool F32>
 __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   constexpr int COLS = 16 * NW;
   constexpr int CH = COLS - 16;
-  constexpr int CSTR = COLS + 1;          // LDS row stride of the MFCC chunk
+  constexpr int CSTR = kMfccCstr;         // LDS row stride of the MFCC chunk (the DCT tile writes of rows 4 apart miss each other's banks)
   constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
   extern __shared__ __align__(16) float lds[];
   STAMP_INIT;
@@ -595,9 +595,16 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
 
   float* kshift = lds + kBShift;
   double* dct = (double*)(lds + kBDct);
+  const float* dct32 = lds + kBDct;               // F32: float A operands, then the float64 row sums of the coefficients
   const int nd = a.dct_rb * a.dct_groups * 256;
-  float* chunk = lds + kBDct + 2 * nd;
-  for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
+  const double* rowsum = (const double*)(lds + kBDct + nd);
+  float* chunk = lds + kBDct + (F32 ? nd + 2 * 16 * a.dct_rb : 2 * nd);
+  if (F32) {
+    for (int i = tid * 4; i < nd; i += NT * 4) *(float4*)(lds + kBDct + i) = *(const float4*)(a.dct_pack32 + i);
+    for (int i = tid; i < 16 * a.dct_rb; i += NT) ((double*)(lds + kBDct + nd))[i] = a.dct_rowsum[i];
+  } else {
+    for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
+  }
   float ps[RPW][6];
 #pragma unroll
   for (int i = 0; i < RPW; ++i)
@@ -619,42 +626,101 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   for (int t0 = 0; t0 < T; t0 += CH) {
     __syncthreads();
     STAMP(9);  // barrier
-    {
-      const double* dp = dct + lane * 4;
-      f64x4 acc[3];
-#pragma unroll
-      for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // a wave whose 16 columns all lie past the last frame the delta filters can reach has nothing to compute
+    // (only in a clip's last chunk; wave-uniform)
+    const bool tile_live = t0 - 8 + wave * 16 <= T - 1;
+    if (!tile_live) {
+    } else if constexpr (F32) {
+      // float32 MFMA on mean-free columns: with x' = x - m (m = any per-frame constant near the column mean)
+      // D x = D x' + m * rowsum(D) exactly, the sums the MFMA carries stay small (silent / clamped frames give
+      // x' = 0 and an exact result) and only the m * rowsum term -- sqrt(n_mels) * m for coefficient 0, ~1e-16 * m
+      // for the others -- is added in float64.
+      const float* dp = dct32 + lane * 4;
+      float4 xq[NG];  // this chunk's rows (the next chunk's fetch below reuses pf)
+      float sum = 0.f;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g < a.dct_groups) {
-          const float4 b4 = pf[g];
           const int m0 = 16 * g + 4 * (lane >> 4);
-          double bv[4];
-          bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
-          bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
-          bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
-          bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
-#pragma unroll
-          for (int rb = 0; rb < 3; ++rb) {
-            if (rb < a.dct_rb) {
-              const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
-              const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
-              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, bv[3], acc[rb], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep one group's operands live at a time (the kernel sits at its VGPR cap)
+          xq[g].x = (m0 + 0 < a.n_mels) ? fmaxf(pf[g].x, floor_db) : 0.f;
+          xq[g].y = (m0 + 1 < a.n_mels) ? fmaxf(pf[g].y, floor_db) : 0.f;
+          xq[g].z = (m0 + 2 < a.n_mels) ? fmaxf(pf[g].z, floor_db) : 0.f;
+          xq[g].w = (m0 + 3 < a.n_mels) ? fmaxf(pf[g].w, floor_db) : 0.f;
+          sum += (xq[g].x + xq[g].y) + (xq[g].z + xq[g].w);
         }
       }
       fetch(t0 + CH);
+      sum += __shfl_xor(sum, 16);  // the four lanes of a frame (lane & 15) end up with the same total
+      sum += __shfl_xor(sum, 32);
+      const float m32 = sum * a.inv_n_mels;
+      f32x4 acc[3];
+#pragma unroll
+      for (int rb = 0; rb < 3; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g < a.dct_groups) {
+          const int m0 = 16 * g + 4 * (lane >> 4);
+          float bv[4];
+          bv[0] = (m0 + 0 < a.n_mels) ? xq[g].x - m32 : 0.f;
+          bv[1] = (m0 + 1 < a.n_mels) ? xq[g].y - m32 : 0.f;
+          bv[2] = (m0 + 2 < a.n_mels) ? xq[g].z - m32 : 0.f;
+          bv[3] = (m0 + 3 < a.n_mels) ? xq[g].w - m32 : 0.f;
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) {
+            if (rb < a.dct_rb) {
+              const float4 a4 = *(const float4*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bv[0], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bv[1], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bv[2], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bv[3], acc[rb], 0, 0, 0);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int rb = 0; rb < 3; ++rb)
         if (rb < a.dct_rb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
-            chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
+          for (int r = 0; r < 4; ++r) {  // f32 C/D map: row = 4 * (lane >> 4) + reg, col = lane & 15
+            const int row = rb * 16 + 4 * (lane >> 4) + r;
+            chunk[row * CSTR + wave * 16 + (lane & 15)] = (float)((double)acc[rb][r] + (double)m32 * rowsum[row]);
+          }
+    } else {
+        const double* dp = dct + lane * 4;
+        f64x4 acc[3];
+  #pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+  #pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g < a.dct_groups) {
+            const float4 b4 = pf[g];
+            const int m0 = 16 * g + 4 * (lane >> 4);
+            double bv[4];
+            bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
+            bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
+            bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
+            bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
+  #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+              if (rb < a.dct_rb) {
+                const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
+                const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
+                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, bv[3], acc[rb], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep one group's operands live at a time (the kernel sits at its VGPR cap)
+          }
+        }
+        fetch(t0 + CH);
+  #pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+          if (rb < a.dct_rb)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
+              chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
     }
     STAMP(10);  // DCT
     __syncthreads();
@@ -927,8 +993,11 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
   }
 }
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4>, grid, 512, lds_bytes, s, a);
-  return launch_one(dysf_mfcc_kernel<512, 8>, grid, 512, lds_bytes, s, a);
+  // up to 64 mels: mean-free float32 MFMA.  The eight-group form of it spills its statistics accumulators, so the
+  // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tools/margin.py).
+  if (a.dct_pack32 && a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, true>, grid, 512, lds_bytes, s, a);
+  if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);
 }
 hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   switch (n_fft) {

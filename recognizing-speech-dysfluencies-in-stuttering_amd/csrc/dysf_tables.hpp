@@ -66,6 +66,8 @@ struct HostTables {
   std::vector<float> chroma;     // [100][12][n_bins]   (only when p.chroma)
   MfmaPack mel_pack, dct_pack;
   std::vector<double> dct_pack64;  // exact float64 coefficients, K-grouped layout (see build_tables)
+  std::vector<float> dct_pack32;   // the float32 coefficients in the same layout
+  std::vector<double> dct_rowsum;  // [16 * row blocks] float64 sum over mels of every row's float32 coefficients
   int dct_groups = 0;               // groups of 16 mels = mpad / 16
   std::vector<float> chroma_pack;  // [100][chroma_steps*64]
   int chroma_steps = 0;
@@ -202,6 +204,10 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
     const int groups = t.mpad / 16;
     t.dct_groups = groups;
     t.dct_pack64.assign((size_t)t.dct_pack.row_blocks * groups * 64 * 4, 0.0);
+    t.dct_pack32.assign(t.dct_pack64.size(), 0.f);
+    t.dct_rowsum.assign((size_t)t.dct_pack.row_blocks * 16, 0.0);
+    for (int c = 0; c < p.n_mfcc; ++c)
+      for (int m = 0; m < p.n_mels; ++m) t.dct_rowsum[c] += (double)t.dct[(size_t)c * p.n_mels + m];
     for (int rb = 0; rb < t.dct_pack.row_blocks; ++rb)
       for (int g = 0; g < groups; ++g)
         for (int l = 0; l < 64; ++l)
@@ -211,6 +217,7 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
               double d = std::cos(M_PI * (double)c * (2.0 * m + 1.0) / (2.0 * M)) * std::sqrt(2.0 / M);
               if (c == 0) d *= std::sqrt(0.5);
               t.dct_pack64[(((size_t)rb * groups + g) * 64 + l) * 4 + s] = d;
+              t.dct_pack32[(((size_t)rb * groups + g) * 64 + l) * 4 + s] = t.dct[(size_t)c * p.n_mels + m];
             }
           }
   }
