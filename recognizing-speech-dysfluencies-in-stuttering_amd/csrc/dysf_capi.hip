@@ -47,6 +47,7 @@ struct DysfHandle {
   int num_cu = 256;
   size_t lds_limit = 163840;
   // device tables
+  float* d_window_i16 = nullptr;
   float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr, *d_mel_pack = nullptr,
         *d_chroma_pack = nullptr;
   double* d_dct_pack = nullptr;
@@ -63,7 +64,7 @@ struct DysfHandle {
   hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   DevBuf st_pcm, st_off, st_pooled, st_frames, st_status, st_tuning;
-  DevBuf d_mel_sched;
+  DevBuf d_mel_sched, d_mel_spack;  // kernel A's per-wave mel schedule and the taps laid out in its order
   int mel_slots = 0;
 };
 
@@ -113,6 +114,11 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
       h->lds_limit = (size_t)v;
     rc |= upload(&h->d_window, h->t.window_half);
+    {
+      std::vector<float> w16(h->t.window_half);
+      for (float& w : w16) w *= 1.0f / 32768.0f;  // exact
+      rc |= upload(&h->d_window_i16, w16);
+    }
     rc |= upload(&h->d_stage_tw, h->t.stage_tw);
     rc |= upload(&h->d_post_tw, h->t.post_tw);
     rc |= upload(&h->d_mel_pack, h->t.mel_pack.data);
@@ -132,11 +138,11 @@ void dysf_destroy(DysfHandle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
-    (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum);
+    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum);
     (void)hipFree(h->d_chroma_pack);
     h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
-    h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release();
+    h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
     for (int i = 0; i < 4; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   }
   delete h;
@@ -192,7 +198,10 @@ int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out16, int32_t reset) {
 // ------------------------------------------------------------------------------------------------
 // Mel schedule: every (column block, row block) band is a run of K-steps; runs are dealt to the waves in order with
 // a per-wave budget of ceil(total / waves), splitting a band across waves where needed (partial sums meet in LDS).
-static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::vector<int32_t>& sched, int* nslots) {
+// The taps of every segment are re-laid into `spack`, zero-padded to whole batches of eight K-steps, so the kernel
+// needs no tap mask: the steps past a segment's end multiply by zero.
+static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::vector<int32_t>& sched, int* nslots,
+                               std::vector<float>& spack) {
   const int stride = kMelSchedStride;
   sched.assign((size_t)nw * stride, 0);
   const MfmaPack& mp = t.mel_pack;
@@ -218,7 +227,11 @@ static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::v
           int take = (w == wend) ? rem : std::min(rem, cap);
           if (w < wend && rem - take > 0 && rem - take < 4) take = rem;  // no slivers
           int* q = &sched[(size_t)w * stride + (size_t)std::min(nseg, kMelMaxSeg - 1) * 8];
-          q[0] = rb; q[1] = cb; q[2] = kbeg + 4 * s0; q[3] = take; q[4] = poff + s0 * 64; q[5] = 0; q[6] = 0; q[7] = 0;
+          const int soff = (int)spack.size();
+          spack.resize(soff + (size_t)((take + 7) / 8 * 8) * 64, 0.f);
+          std::copy(mp.data.begin() + poff + (size_t)s0 * 64, mp.data.begin() + poff + (size_t)(s0 + take) * 64,
+                    spack.begin() + soff);
+          q[0] = rb; q[1] = cb; q[2] = kbeg + 4 * s0; q[3] = take; q[4] = soff; q[5] = 0; q[6] = 0; q[7] = 0;
           parts.push_back({w, std::min(nseg, kMelMaxSeg - 1)});
           if (nseg < kMelMaxSeg) ++nseg;
           s0 += take; rem -= take; cap -= take;
@@ -253,7 +266,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const DysfParams& p = t.p;
   const int64_t t_max = 1 + max_samples / p.hop;
   if (d_frames && frame_stride < t_max) return fail(DYSF_E_INVALID, "frame_stride smaller than the longest clip's frame count");
-  if (t_max > (1 << 24)) return fail(DYSF_E_INVALID, "clip too long");
+  if (t_max > (1 << 24) || max_samples > 0x7ff00000LL) return fail(DYSF_E_INVALID, "clip too long");
   HIPCHK(hipSetDevice(h->device));
 
   KArgs a;
@@ -262,8 +275,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.pooled_dim = dysf_pooled_dim(h); a.frame_stride = frame_stride;
   a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel; a.dbg_stamps = h->dbg_stamps;
   a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
-  a.window = h->d_window; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
-  a.mel_pack = h->d_mel_pack;
+  a.window = h->d_window; a.window_i16 = h->d_window_i16; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_groups = t.dct_groups;
   a.dct_pack32 = h->dct64 ? nullptr : h->d_dct_pack32; a.dct_rowsum = h->d_dct_rowsum; a.inv_n_mels = 1.0f / (float)p.n_mels;
   a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
@@ -277,12 +289,16 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.rstride = rstride;
   if (!h->sched_built) {
     std::vector<int32_t> sched;
-    build_mel_schedule(t, nw_a, cb_a, sched, &h->mel_slots);
+    std::vector<float> spack;
+    build_mel_schedule(t, nw_a, cb_a, sched, &h->mel_slots, spack);
     if (int rc = h->d_mel_sched.reserve(sched.size() * 4)) return rc;
     HIPCHK(hipMemcpy(h->d_mel_sched.p, sched.data(), sched.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = h->d_mel_spack.reserve(spack.size() * 4)) return rc;
+    HIPCHK(hipMemcpy(h->d_mel_spack.p, spack.data(), spack.size() * 4, hipMemcpyHostToDevice));
     h->sched_built = true;
   }
   a.mel_sched = (const int*)h->d_mel_sched.p;
+  a.mel_pack = (const float*)h->d_mel_spack.p;
   a.mel_slots = h->mel_slots;
   a.tiles_per_wg = 4;
   if (const char* e = std::getenv("DYSF_TILES")) { if (std::atoi(e) > 0) a.tiles_per_wg = std::atoi(e); }

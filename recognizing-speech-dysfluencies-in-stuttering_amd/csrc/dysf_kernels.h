@@ -30,6 +30,7 @@ struct KArgs {
   int tiles_per_wg;  // kernel A: consecutive frame tiles one workgroup processes
   // tables
   const float* window;    // pre-scaled by 1/2
+  const float* window_i16;  // the same times 2^-15: int16 PCM is staged as unscaled integers
   const float* stage_tw;
   const float* post_tw;
   const float* mel_pack;

@@ -43,7 +43,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // PCM tile staging in two halves so the HBM latency hides under the previous tile's FFT:
 //   pcm_prefetch  issues 16-byte coalesced loads of the samples [s0, s0 + count) of a clip into registers
-//   pcm_commit    converts (int16 * 2^-15 is exact) and writes them to the LDS tile as float32
+//   pcm_commit    converts and writes them to the LDS tile as float32 (int16 stays unscaled: see pcm_store_group)
 // The tile is stored from the 16-byte-aligned element a0 <= off + s0 onwards, so element (off + s) sits at
 // tile[(off + s) - a0] and every group lands on an aligned ds_write_b128; samples outside [0, n) are zero.
 template <int PCM>
@@ -53,30 +53,33 @@ struct PcmStage {
   int4 g[MAXG];                                                        // beyond MAXG*NT groups is staged in place
 };
 
+// All positions are 32-bit and relative to the clip's first sample (clips are shorter than 2^31 samples); `base`
+// points at that sample.  off_lo = off & (EPG - 1) carries the clip's alignment inside its 16-byte group.
 template <int PCM>
-__device__ __forceinline__ long long pcm_tile_origin(long long off, long long s0) {
-  return (off + s0) & ~(long long)(PcmStage<PCM>::EPG - 1);  // floor, also for negative values
+__device__ __forceinline__ int pcm_tile_origin(int off_lo, int s0) {
+  return ((off_lo + s0) & ~(PcmStage<PCM>::EPG - 1)) - off_lo;  // floor to a 16-byte group, also for negative values
 }
 
 template <int PCM>
-__device__ __forceinline__ int4 pcm_load_group(const void* pcm, long long off, long long n, long long a) {
+__device__ __forceinline__ int4 pcm_load_group(const char* base, int n, int r) {
   constexpr int EPG = PcmStage<PCM>::EPG;
+  constexpr int ES = (PCM == DYSF_PCM_I16) ? 2 : 4;
   int4 v = make_int4(0, 0, 0, 0);
-  if (a >= off && a + EPG <= off + n) {
-    v = *(const int4*)((const char*)pcm + a * (PCM == DYSF_PCM_I16 ? 2 : 4));
-  } else if (a + EPG > off && a < off + n) {  // straddles a clip edge: element-wise, zero outside
+  if (r >= 0 && r + EPG <= n) {
+    v = *(const int4*)(base + (long long)r * ES);
+  } else if (r + EPG > 0 && r < n) {  // straddles a clip edge: element-wise, zero outside
     if (PCM == DYSF_PCM_I16) {
-      const unsigned short* b = (const unsigned short*)pcm;
+      const unsigned short* b = (const unsigned short*)base;
       unsigned e[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) e[i] = (a + i >= off && a + i < off + n) ? (unsigned)b[a + i] : 0u;
+      for (int i = 0; i < 8; ++i) e[i] = (r + i >= 0 && r + i < n) ? (unsigned)b[r + i] : 0u;
       v = make_int4((int)(e[0] | (e[1] << 16)), (int)(e[2] | (e[3] << 16)), (int)(e[4] | (e[5] << 16)),
                     (int)(e[6] | (e[7] << 16)));
     } else {
-      const int* b = (const int*)pcm;
+      const int* b = (const int*)base;
       int e[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) e[i] = (a + i >= off && a + i < off + n) ? b[a + i] : 0;
+      for (int i = 0; i < 4; ++i) e[i] = (r + i >= 0 && r + i < n) ? b[r + i] : 0;
       v = make_int4(e[0], e[1], e[2], e[3]);
     }
   }
@@ -87,12 +90,12 @@ __device__ __forceinline__ int4 pcm_load_group(const void* pcm, long long off, l
 template <int PCM>
 __device__ __forceinline__ bool pcm_store_group(float* tile, int gi, int4 v) {
   if (PCM == DYSF_PCM_I16) {
-    constexpr float sc = 1.0f / 32768.0f;
+    // the 2^-15 of int16 -> [-1, 1) is folded into the window table (KArgs::window_i16; exact, a power of two)
     float4 lo, hi;
-    lo.x = (float)(short)(v.x & 0xffff) * sc; lo.y = (float)(v.x >> 16) * sc;
-    lo.z = (float)(short)(v.y & 0xffff) * sc; lo.w = (float)(v.y >> 16) * sc;
-    hi.x = (float)(short)(v.z & 0xffff) * sc; hi.y = (float)(v.z >> 16) * sc;
-    hi.z = (float)(short)(v.w & 0xffff) * sc; hi.w = (float)(v.w >> 16) * sc;
+    lo.x = (float)(short)(v.x & 0xffff); lo.y = (float)(v.x >> 16);
+    lo.z = (float)(short)(v.y & 0xffff); lo.w = (float)(v.y >> 16);
+    hi.x = (float)(short)(v.z & 0xffff); hi.y = (float)(v.z >> 16);
+    hi.z = (float)(short)(v.w & 0xffff); hi.w = (float)(v.w >> 16);
     *(float4*)(tile + gi * 8) = lo;
     *(float4*)(tile + gi * 8 + 4) = hi;
     return false;
@@ -104,19 +107,17 @@ __device__ __forceinline__ bool pcm_store_group(float* tile, int gi, int4 v) {
 }
 
 template <int PCM, int NT>
-__device__ __forceinline__ void pcm_prefetch(PcmStage<PCM>& st, const void* pcm, long long off, long long n,
-                                             long long a0, int ngroups) {
+__device__ __forceinline__ void pcm_prefetch(PcmStage<PCM>& st, const char* base, int n, int r0, int ngroups) {
 #pragma unroll
   for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
     const int gi = threadIdx.x + j * NT;
-    st.g[j] = (gi < ngroups) ? pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG)
-                             : make_int4(0, 0, 0, 0);
+    st.g[j] = (gi < ngroups) ? pcm_load_group<PCM>(base, n, r0 + gi * PcmStage<PCM>::EPG) : make_int4(0, 0, 0, 0);
   }
 }
 
 template <int PCM, int NT>
-__device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile, const void* pcm, long long off,
-                                           long long n, long long a0, int ngroups) {
+__device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile, const char* base, int n, int r0,
+                                           int ngroups) {
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ bool pcm_commit(const PcmStage<PCM>& st, float* tile,
     if (gi < ngroups) bad |= pcm_store_group<PCM>(tile, gi, st.g[j]);
   }
   for (int gi = threadIdx.x + PcmStage<PCM>::MAXG * NT; gi < ngroups; gi += NT)  // oversized tiles
-    bad |= pcm_store_group<PCM>(tile, gi, pcm_load_group<PCM>(pcm, off, n, a0 + (long long)gi * PcmStage<PCM>::EPG));
+    bad |= pcm_store_group<PCM>(tile, gi, pcm_load_group<PCM>(base, n, r0 + gi * PcmStage<PCM>::EPG));
   return bad;
 }
 
@@ -152,13 +153,14 @@ struct FftTabs {     // LDS tables shared by the workgroup (consecutive lanes ->
 };
 
 // copy the tables from global memory (once per workgroup)
-template <int NC, int NT>
+template <int NC, int NT, int PCM>
 __device__ __forceinline__ void load_fft_tabs(float* dst, const KArgs& a, FftTabs& t) {
   constexpr int L = FftGeom<NC>::L;
   float* win = dst;
   float* ptw = win + 2 * NC;
   cf* t1 = (cf*)(ptw + ((NC + 2 + 3) & ~3));
-  for (int i = threadIdx.x; i < 2 * NC; i += NT) win[i] = a.window[i];
+  const float* wsrc = (PCM == DYSF_PCM_I16) ? a.window_i16 : a.window;
+  for (int i = threadIdx.x; i < 2 * NC; i += NT) win[i] = wsrc[i];
   for (int i = threadIdx.x; i < NC + 2; i += NT) ptw[i] = a.post_tw[i];
   for (int i = threadIdx.x; i < kPts * L; i += NT) t1[i] = ((const cf*)a.stage_tw)[(i % L) * kPts + (i / L)];
   t.win = win; t.ptw = ptw; t.t1 = t1;
@@ -331,18 +333,16 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   f = f < FPI ? f : FPI - 1;
   const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad + g.kbeg + (lane >> 4);
   const float* wp = mel_src + g.poff + lane;  // LDS copy when it fits, else the L2-resident global pack
-  const int krem = NC - g.kbeg - (lane >> 4);  // B row valid while 4*s <= krem
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA latency
-  // batches of 8 K-steps: 16 LDS reads in flight, then 8 MFMAs; steps past the end of the segment multiply by a
-  // zero tap (the pack is padded so the speculative tap reads stay inside it)
+  // batches of 8 K-steps: 16 LDS / L2 reads in flight, then 8 MFMAs.  No masks: the host pads every segment's taps
+  // with zeros to a whole batch, and the spectrum reads that run past bin NC stay inside the workgroup's LDS, which
+  // holds finite values only (regions are zeroed at start-up; a clip with non-finite samples is rejected anyway).
   for (int s = 0; s < g.nsteps; s += 8) {
     float av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) bv[u] = (4 * (s + u) <= krem) ? srow[4 * (s + u)] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) av[u] = (s + u < g.nsteps) ? av[u] : 0.f;
+    for (int u = 0; u < 8; ++u) bv[u] = srow[4 * (s + u)];
 #pragma unroll
     for (int u = 0; u < 8; u += 2) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
@@ -438,7 +438,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * a.kpad;
   FftTabs tb;
-  load_fft_tabs<NC, NT>(lds + a.lds_tables, a, tb);
+  load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
+  // the mel product reads a few words past a spectrum row's last bin (see mel_segment): no stale LDS there
+  for (int i = tid * 4; i < NW * a.rstride; i += NT * 4) *(float4*)(regions + i) = float4{0.f, 0.f, 0.f, 0.f};
   int* sched = imisc + 32;
   for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
   const int* wsched = sched + wave * kMelSchedStride;
@@ -453,25 +455,26 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   bool bad = false;
   const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
   PcmStage<PCM> stage;
-  auto tile_geom = [&](int ti, long long* a0, int* shift, int* ngroups) {
-    const long long s0 = (long long)ti * FPI * a.hop - NC;
-    *a0 = pcm_tile_origin<PCM>(off, s0);
-    *shift = (int)(off + s0 - *a0);
-    *ngroups = (int)((off + s0 + tile_samples - *a0 + EPG - 1) / EPG);
+  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
+  const int n32 = (int)n, off_lo = (int)(off & (EPG - 1));
+  auto tile_geom = [&](int ti, int* r0, int* shift, int* ngroups) {
+    const int s0 = ti * FPI * a.hop - NC;
+    *r0 = pcm_tile_origin<PCM>(off_lo, s0);
+    *shift = s0 - *r0;
+    *ngroups = (s0 + tile_samples - *r0 + EPG - 1) / EPG;
   };
-  long long a0 = 0;
-  int shift = 0, ngroups = 0;
-  tile_geom(ti0, &a0, &shift, &ngroups);
-  pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
-  bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
+  int r0 = 0, shift = 0, ngroups = 0;
+  tile_geom(ti0, &r0, &shift, &ngroups);
+  pcm_prefetch<PCM, NT>(stage, pbase, n32, r0, ngroups);
+  bad |= pcm_commit<PCM, NT>(stage, tile, pbase, n32, r0, ngroups);
   __syncthreads();
   STAMP(0);  // setup: tables, schedule, first tile staged
   for (int j = 0; j < ntiles; ++j) {
     const int f0 = (ti0 + j) * FPI;
     const int cur_shift = shift;
     if (j + 1 < ntiles) {  // loads for the next tile fly while this one is transformed
-      tile_geom(ti0 + j + 1, &a0, &shift, &ngroups);
-      pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, a0, ngroups);
+      tile_geom(ti0 + j + 1, &r0, &shift, &ngroups);
+      pcm_prefetch<PCM, NT>(stage, pbase, n32, r0, ngroups);
     }
     {
       const int fl = wave * FPW + q;  // frame within tile
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
     STAMP(1);  // prefetch issue + FFT
     __syncthreads();  // S tile complete; every wave is done reading the PCM tile
     STAMP(2);  // barrier
-    if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, a0, ngroups);
+    if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, pbase, n32, r0, ngroups);
     if (a.dbg_S) {
       for (int i = tid; i < FPI * (NC + 1); i += NT) {
         const int f = i / (NC + 1), k = i % (NC + 1);
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * a.kpad;
   FftTabs tb;
-  load_fft_tabs<NC, NT>(lds + a.lds_tables, a, tb);
+  load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
   float* prow = a.pooled + (size_t)clip * a.pooled_dim;
   const float* pk_mag = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
   const int* pk_bin = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
@@ -878,18 +881,20 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   float cshift = 0.f;
   const int ntiles = (T + FPI - 1) / FPI;
   const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
+  const int n32 = (int)n, off_lo = (int)(off & (EPG - 1));
   for (int ti = 0; ti < ntiles; ++ti) {
     const int f0 = ti * FPI;
-    const long long cs0 = (long long)f0 * a.hop - NC;
-    const long long ca0 = pcm_tile_origin<PCM>(off, cs0);
+    const int cs0 = f0 * a.hop - NC;
+    const int cr0 = pcm_tile_origin<PCM>(off_lo, cs0);
     {
       PcmStage<PCM> stage;
-      const int cng = (int)((off + cs0 + tile_samples - ca0 + EPG - 1) / EPG);
-      pcm_prefetch<PCM, NT>(stage, a.pcm, off, n, ca0, cng);
-      pcm_commit<PCM, NT>(stage, tile, a.pcm, off, n, ca0, cng);
+      const int cng = (cs0 + tile_samples - cr0 + EPG - 1) / EPG;
+      pcm_prefetch<PCM, NT>(stage, pbase, n32, cr0, cng);
+      pcm_commit<PCM, NT>(stage, tile, pbase, n32, cr0, cng);
     }
     __syncthreads();
-    wave_frame_power<NC>(tile + (int)(off + cs0 - ca0), (wave * FPW + q) * a.hop, xb, srow_own, ls, tb, a);
+    wave_frame_power<NC>(tile + (cs0 - cr0), (wave * FPW + q) * a.hop, xb, srow_own, ls, tb, a);
     __syncthreads();
     const int sb = (a.chroma_steps * wave) / NW, se = (a.chroma_steps * (wave + 1)) / NW;
     for (int cb = 0; cb < CB; ++cb) {
