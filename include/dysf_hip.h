@@ -152,6 +152,28 @@ void    dysf_forest_destroy(DysfForest* f);
 int32_t dysf_forest_predict_dev(DysfForest* f, const float* d_x, int32_t n, double* d_proba, int32_t* d_pred,
                                 void* stream);
 
+/*
+ * RBF support-vector classifier inference: replaces scaler.transform + SVC.predict /
+ * SVC.predict_proba / decision_function(ovo) of pipeline1.py:498, 512-514 (main1.py:865 soft-votes it with the
+ * forest and the MLP).  The model is given as scikit-learn exposes the fitted libsvm model:
+ *   support_vectors [n_sv, n_features] (grouped by class), dual_coef [n_classes-1, n_sv], intercept [n_pairs]
+ *   (= -rho), n_support [n_classes], prob_a / prob_b [n_pairs] (Platt coefficients; both NULL for a model fitted
+ *   without probability=True), gamma (the resolved value, SVC._gamma), mean / scale [n_features] of the scaler.
+ *   d_x         [n, n_features] float32 UNscaled feature rows (device)
+ *   d_decision  [n, n_pairs] float64 pair decision values in the order (0,1), (0,2), ..., (1,2), ... or NULL
+ *   d_proba     [n, n_classes] float64 (pairwise-coupled Platt probabilities) or NULL
+ *   d_pred      [n] int32 (one-vs-one vote, first maximum -- what SVC.predict returns) or NULL
+ */
+typedef struct DysfSvc DysfSvc;
+const char* dysf_svc_last_error(void);
+int32_t dysf_svc_create(int32_t device, int32_t n_features, int32_t n_classes, int32_t n_sv,
+                        const double* support_vectors, const double* dual_coef, const double* intercept,
+                        const int32_t* n_support, const double* prob_a, const double* prob_b, double gamma,
+                        const double* mean, const double* scale, DysfSvc** out);
+void    dysf_svc_destroy(DysfSvc* m);
+int32_t dysf_svc_predict_dev(DysfSvc* m, const float* d_x, int32_t n, double* d_decision, double* d_proba,
+                             int32_t* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ SYMBOLS = (
     "dysf_extract_batch_dev", "dysf_extract_batch", "dysf_debug_stft_power_dev", "dysf_debug_logmel_dev",
     "dysf_debug_timing", "dysf_debug_peaks",
     "dysf_forest_last_error", "dysf_forest_create", "dysf_forest_destroy", "dysf_forest_predict_dev",
+    "dysf_svc_last_error", "dysf_svc_create", "dysf_svc_destroy", "dysf_svc_predict_dev",
 )
 
 
@@ -78,6 +79,11 @@ def lib():
     L.dysf_forest_destroy.argtypes = [vp]
     L.dysf_forest_destroy.restype = None
     L.dysf_forest_predict_dev.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.dysf_svc_last_error.restype = ctypes.c_char_p
+    L.dysf_svc_create.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, ctypes.POINTER(vp)]
+    L.dysf_svc_destroy.argtypes = [vp]
+    L.dysf_svc_destroy.restype = None
+    L.dysf_svc_predict_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

@@ -123,6 +123,103 @@ class RandomForestHead:
             pass
 
 
+class SVCHead:
+    """scaler.transform + SVC(kernel='rbf', probability=True).predict / predict_proba / decision_function(ovo)
+    (pipeline1.py:498, 512-514; main1.py:865) on the GPU: a HIP kernel behind the C ABI (``dysf_svc_*``) that follows
+    libsvm's prediction algorithm.  Built from the arrays scikit-learn exposes on a fitted SVC (see
+    tests/golden/make_golden.py: svc_fixture)."""
+
+    def __init__(self, support_vectors, dual_coef, intercept, n_support, gamma, mean, scale, prob_a=None, prob_b=None,
+                 classes=None, device: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.device = device
+        sv = np.ascontiguousarray(support_vectors, np.float64)
+        self.n_classes = int(np.asarray(n_support).shape[0])
+        self.n_pairs = self.n_classes * (self.n_classes - 1) // 2
+        self.n_features_in_ = int(sv.shape[1])
+        self.has_proba = prob_a is not None and len(np.atleast_1d(prob_a)) > 0
+        self.classes = None if classes is None else [str(c) for c in classes]
+        vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        arrs = dict(sv=sv, dc=np.ascontiguousarray(dual_coef, np.float64), ic=np.ascontiguousarray(intercept, np.float64),
+                    ns=np.ascontiguousarray(n_support, np.int32),
+                    pa=np.ascontiguousarray(prob_a, np.float64) if self.has_proba else None,
+                    pb=np.ascontiguousarray(prob_b, np.float64) if self.has_proba else None,
+                    mean=np.ascontiguousarray(mean, np.float64), scale=np.ascontiguousarray(scale, np.float64))
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.dysf_svc_create(device, self.n_features_in_, self.n_classes, sv.shape[0], vp(arrs["sv"]), vp(arrs["dc"]),
+                               vp(arrs["ic"]), vp(arrs["ns"]), vp(arrs["pa"]), vp(arrs["pb"]), float(gamma),
+                               vp(arrs["mean"]), vp(arrs["scale"]), ctypes.byref(self._h))
+        if rc != 0:
+            raise _lib.DysfError(f"dysf_svc_create failed ({rc}): {L.dysf_svc_last_error().decode()}")
+
+    @classmethod
+    def from_npz(cls, path: str, classes=None, device: int = 0) -> "SVCHead":
+        z = np.load(path, allow_pickle=False)
+        return cls(z["support_vectors"], z["dual_coef"], z["intercept"], z["n_support"], float(z["gamma"]), z["mean"],
+                   z["scale"], z["prob_a"], z["prob_b"], classes=classes, device=device)
+
+    def _run(self, x: torch.Tensor, want_proba: bool = True):
+        import ctypes
+        if x.shape[-1] != self.n_features_in_:
+            raise ValueError(f"Feature mismatch! Expected {self.n_features_in_}, got {x.shape[-1]}.")
+        x = x.to(torch.float32).contiguous()
+        assert x.is_cuda
+        n = x.shape[0]
+        dec = torch.empty((n, self.n_pairs), dtype=torch.float64, device=x.device)
+        proba = torch.empty((n, self.n_classes), dtype=torch.float64, device=x.device) if want_proba and self.has_proba else None
+        pred = torch.empty(n, dtype=torch.int32, device=x.device)
+        L = self._lib.lib()
+        rc = L.dysf_svc_predict_dev(self._h, ctypes.c_void_p(x.data_ptr()), n, ctypes.c_void_p(dec.data_ptr()),
+                                    ctypes.c_void_p(proba.data_ptr()) if proba is not None else None,
+                                    ctypes.c_void_p(pred.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.DysfError(f"dysf_svc_predict_dev failed ({rc}): {L.dysf_svc_last_error().decode()}")
+        return dec, proba, pred
+
+    def decision_function(self, x: torch.Tensor) -> torch.Tensor:
+        """Pair decision values in one-vs-one order (decision_function_shape='ovo')."""
+        return self._run(x, want_proba=False)[0]
+
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.has_proba:
+            raise AttributeError("predict_proba is not available when probability=False")  # sklearn's own message
+        return self._run(x)[1]
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, want_proba=False)[2].to(torch.int64)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lib().dysf_svc_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SoftVotingHead:
+    """VotingClassifier(voting='soft') of main1.py:867: the arithmetic mean of the members' predict_proba, arg-max
+    (first maximum).  Members are heads of this module; they all take the same UNscaled float32 rows."""
+
+    def __init__(self, members, classes=None):
+        self.members = list(members)
+        self.classes = None if classes is None else [str(c) for c in classes]
+
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        ps = [m.predict_proba(x).to(torch.float64) for m in self.members]
+        return torch.stack(ps).mean(0)
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        return self.predict_proba(x).argmax(-1)
+
+
 class CNNHead(nn.Module):
     """Conv2d(1->32,3x3,p1) ReLU MaxPool2 Conv2d(32->64,3x3,p1) ReLU global-avg-pool Linear(64->3) on
     [B, 1, 3*n_mfcc, T] frame-level features; random weights from ``torch.manual_seed(seed)``."""

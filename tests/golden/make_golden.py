@@ -195,11 +195,58 @@ def forest_fixture():
         evidence=json.dumps(evidence))
 
 
+def svc_fixture():
+    """SVC(probability=True, kernel='rbf', C=1.0, random_state=42) re-fit exactly as pipeline1.py:498, 512-514 does on the
+    cleaned ("after") features; exported as the libsvm model arrays (support vectors, dual coefficients, intercepts,
+    Platt A/B) for the GPU kernel, with sklearn's own decision values / predictions / probabilities as expected outputs."""
+    from sklearn.metrics import accuracy_score, confusion_matrix, log_loss
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import LabelEncoder, StandardScaler
+    from sklearn.svm import SVC
+
+    files = list_audio_files(os.path.join(REF, "segrigated_samples"))
+    labels = [os.path.basename(os.path.dirname(f)) for f in files]
+    X_after = np.vstack([np.load(os.path.join(REF, "cache_features",
+                                              os.path.basename(f).rsplit(".", 1)[0] + "_clean_feats.npy"))
+                         for f in files])
+    y = LabelEncoder().fit_transform(labels)
+    scaler = StandardScaler().fit(X_after)
+    Xs = scaler.transform(X_after)
+    Xtr, Xte, ytr, yte = train_test_split(Xs, y, test_size=0.2, stratify=y, random_state=42)
+    svc = SVC(probability=True, kernel="rbf", C=1.0, random_state=42).fit(Xtr, ytr)
+    pred_te, proba_te = svc.predict(Xte), svc.predict_proba(Xte)
+    acc, loss = float(accuracy_score(yte, pred_te) * 100.0), float(log_loss(yte, proba_te))
+    cm = confusion_matrix(yte, pred_te)
+    with open(os.path.join(REF, "output_results", "confusion_after_SVM.csv")) as f:
+        ref_cm = np.array([[int(v) for v in row[1:]] for row in list(csv.reader(f))[1:]])
+    ref_row = None
+    with open(os.path.join(REF, "output_results", "metrics_summary.csv")) as f:
+        for row in csv.DictReader(f):
+            if row["dataset"] == "after" and row["model"] == "SVM":
+                ref_row = [float(row["accuracy"]), float(row["test_loss"])]
+    evidence = {"accuracy": acc, "log_loss": loss, "confusion_matches_reference": bool((cm == ref_cm).all()),
+                "reference_metrics_summary_after_SVM": ref_row}
+    print(json.dumps(evidence, indent=1))
+    svc.decision_function_shape = "ovo"
+    np.savez_compressed(
+        os.path.join(HERE, "svc_after.npz"),
+        support_vectors=svc.support_vectors_.astype(np.float64), dual_coef=svc.dual_coef_.astype(np.float64),
+        intercept=svc.intercept_.astype(np.float64), prob_a=svc.probA_.astype(np.float64),
+        prob_b=svc.probB_.astype(np.float64), n_support=svc.n_support_.astype(np.int32),
+        gamma=np.float64(svc._gamma), mean=scaler.mean_, scale=scaler.scale_,
+        expected_pred=svc.predict(Xs).astype(np.int64), expected_proba=svc.predict_proba(Xs),
+        expected_decision=svc.decision_function(Xs), evidence=json.dumps(evidence))
+
+
 if __name__ == "__main__":
     if "--forest-only" in sys.argv:
         forest_fixture()
+        sys.exit(0)
+    if "--svc-only" in sys.argv:
+        svc_fixture()
         sys.exit(0)
     lengths = validate_all()
     copy_pairs(lengths)
     classifier_fixture()
     forest_fixture()
+    svc_fixture()

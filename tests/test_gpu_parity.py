@@ -341,3 +341,43 @@ def test_random_forest_head_matches_sklearn_fixture(golden_dir):
     with pytest.raises(ValueError):
         head.predict(torch.zeros(1, 148).cuda())
     head.close()
+
+
+def test_svc_head_matches_sklearn_fixture(golden_dir):
+    """SVC(probability=True, kernel='rbf', C=1.0) of pipeline1.py:498 as a HIP kernel that follows
+    libsvm's prediction algorithm.  Fixture = the SVC re-fit exactly as the reference does (accuracy, log-loss and
+    confusion matrix equal metrics_summary.csv / confusion_after_SVM.csv) with scikit-learn's own outputs.
+    Tolerances: float64 decision values 1e-9, one-vs-one votes exact, coupled Platt probabilities 1e-9."""
+    from rsd_amd.classifier import SVCHead
+    z = np.load(os.path.join(golden_dir, "svc_after.npz"))
+    X = np.load(os.path.join(golden_dir, "classifier_after.npz"))["X"]
+    head = SVCHead.from_npz(os.path.join(golden_dir, "svc_after.npz"))
+    x = torch.from_numpy(X).cuda()
+    dec = head.decision_function(x).cpu().numpy()
+    assert np.abs(dec - z["expected_decision"]).max() <= 1e-9
+    assert np.array_equal(head.predict(x).cpu().numpy(), z["expected_pred"])
+    assert np.abs(head.predict_proba(x).cpu().numpy() - z["expected_proba"]).max() <= 1e-9
+    with pytest.raises(ValueError):
+        head.predict(torch.zeros(1, 148).cuda())
+    head.close()
+
+
+def test_soft_voting_of_the_three_heads(golden_dir):
+    """VotingClassifier(voting='soft') of main1.py:867 over forest + MLP + SVC: mean of the members' probabilities.
+    Expected = the mean of scikit-learn's own per-model probabilities from the three fixtures (MLP within 1e-4)."""
+    from rsd_amd.classifier import MLPHead, RandomForestHead, SVCHead, SoftVotingHead
+    c = np.load(os.path.join(golden_dir, "classifier_after.npz"))
+    f = np.load(os.path.join(golden_dir, "forest_after.npz"))
+    s = np.load(os.path.join(golden_dir, "svc_after.npz"))
+    want = (f["expected_proba"] + c["expected_proba"] + s["expected_proba"]) / 3.0
+    heads = [RandomForestHead.from_npz(os.path.join(golden_dir, "forest_after.npz")),
+             MLPHead.from_npz(os.path.join(golden_dir, "classifier_after.npz")).cuda(),
+             SVCHead.from_npz(os.path.join(golden_dir, "svc_after.npz"))]
+    vote = SoftVotingHead(heads)
+    x = torch.from_numpy(c["X"]).cuda()
+    got = vote.predict_proba(x).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-4
+    margin = np.sort(want, axis=1)
+    clear = (margin[:, -1] - margin[:, -2]) > 1e-3          # rows whose winner is not within the MLP's float32 noise
+    assert np.array_equal(vote.predict(x).cpu().numpy()[clear], want.argmax(1)[clear])
+    assert clear.mean() > 0.95

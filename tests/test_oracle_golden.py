@@ -99,3 +99,18 @@ def test_bench_preset_shapes():
     y = O.pcm16_to_float((np.random.default_rng(1).standard_normal(48000) * 3000).astype(np.int16))
     fr = O.frame_level_stack(y, O.BENCH_512)
     assert fr.shape == (120, 301) and fr.dtype == np.float32 and np.isfinite(fr).all()
+
+
+def test_svc_restatement_reproduces_sklearn(golden_dir):
+    """The libsvm restatement (decision values, one-vs-one votes, Platt + pairwise coupling) against scikit-learn's own
+    outputs for the re-fitted SVC of pipeline1.py:498 on all 905 reference rows."""
+    import json
+    z = np.load(os.path.join(golden_dir, "svc_after.npz"), allow_pickle=False)
+    ev = json.loads(str(z["evidence"]))
+    assert ev["confusion_matches_reference"] and abs(ev["log_loss"] - ev["reference_metrics_summary_after_SVM"][1]) < 1e-9
+    c = np.load(os.path.join(golden_dir, "classifier_after.npz"), allow_pickle=False)
+    xs = O.scale_rows_like_sklearn(c["X"], z["mean"], z["scale"])  # the 905 cached 149-d rows, file-walk order
+    dec = O.svc_decision_ovo(xs, z["support_vectors"], z["dual_coef"], z["intercept"], z["n_support"], float(z["gamma"]))
+    assert np.abs(dec - z["expected_decision"]).max() < 1e-9
+    assert (O.svc_predict(dec, 3) == z["expected_pred"]).all()
+    assert np.abs(O.svc_predict_proba(dec, z["prob_a"], z["prob_b"], 3) - z["expected_proba"]).max() < 1e-9
