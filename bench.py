@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-head", action="store_true",
+                    help="run the MLP head as the eager torch module instead of the one-kernel HIP head (dysf_mlp_*)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step (feature launch + head) into a hipGraph and replay it; measured equal to eager "
                          "launches on MI355X (the head's small GEMMs are GPU time, not launch overhead), so off by default")
@@ -88,7 +90,7 @@ def main():
     import torch.distributed as dist
 
     import rsd_amd
-    from rsd_amd.classifier import MLPHead
+    from rsd_amd.classifier import FusedMLPHead, MLPHead
     from rsd_amd.pipeline import gather_rows
     from rsd_amd.synth import synth_bank
 
@@ -118,9 +120,12 @@ def main():
     T = params.n_frames(N_SAMPLES)
     rng = np.random.default_rng(0)
     dims = [ex.pooled_dim, 128, 64, 3]
-    head = MLPHead(np.zeros(dims[0]), np.ones(dims[0]),
-                   [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)],
-                   [np.zeros(dims[i + 1]) for i in range(3)]).to(dev)
+    head_w = [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)]
+    head_b = [np.zeros(dims[i + 1]) for i in range(3)]
+    if args.eager_head:   # the torch module (seven small launches); the default is the one-kernel HIP head
+        head = MLPHead(np.zeros(dims[0]), np.ones(dims[0]), head_w, head_b).to(dev)
+    else:
+        head = FusedMLPHead(np.zeros(dims[0]), np.ones(dims[0]), head_w, head_b, device=local_rank)
 
     kern_ms = []   # torch events around the whole feature launch (memset + kernels), on the launch stream
     per_kernel = []  # HIP events the library records around each of its kernels (dysf_debug_timing)

@@ -174,6 +174,22 @@ void    dysf_svc_destroy(DysfSvc* m);
 int32_t dysf_svc_predict_dev(DysfSvc* m, const float* d_x, int32_t n, double* d_decision, double* d_proba,
                              int32_t* d_pred, void* stream);
 
+/*
+ * MLP head as one kernel: replaces scaler.transform + MLPClassifier.predict / predict_proba of pipeline1.py:470-473,
+ * 497, 512-514 for rows that are already on the device.  dims = {n_features, hidden..., n_outputs} (n_layers + 1
+ * entries: n_features 1..512, every layer width 1..256; up to 4 layers); weights[l] is coefs_[l] ([dims[l], dims[l+1]] row-major float64),
+ * biases[l] is intercepts_[l]; ReLU between layers (the MLPClassifier default), soft-max on the last layer.
+ *   d_x [n, n_features] float32 UNscaled rows;  d_logits / d_proba [n, n_outputs] float32 or NULL;
+ *   d_pred [n] int32 (first arg-max of the logits) or NULL.  float32 arithmetic.
+ */
+typedef struct DysfMlp DysfMlp;
+const char* dysf_mlp_last_error(void);
+int32_t dysf_mlp_create(int32_t device, int32_t n_layers, const int32_t* dims, const double* const* weights,
+                        const double* const* biases, const double* mean, const double* scale, DysfMlp** out);
+void    dysf_mlp_destroy(DysfMlp* m);
+int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_logits, float* d_proba,
+                             int32_t* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SYMBOLS = (
     "dysf_debug_timing", "dysf_debug_peaks",
     "dysf_forest_last_error", "dysf_forest_create", "dysf_forest_destroy", "dysf_forest_predict_dev",
     "dysf_svc_last_error", "dysf_svc_create", "dysf_svc_destroy", "dysf_svc_predict_dev",
+    "dysf_mlp_last_error", "dysf_mlp_create", "dysf_mlp_destroy", "dysf_mlp_forward_dev",
 )
 
 
@@ -84,6 +85,11 @@ def lib():
     L.dysf_svc_destroy.argtypes = [vp]
     L.dysf_svc_destroy.restype = None
     L.dysf_svc_predict_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.dysf_mlp_last_error.restype = ctypes.c_char_p
+    L.dysf_mlp_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dysf_mlp_destroy.argtypes = [vp]
+    L.dysf_mlp_destroy.restype = None
+    L.dysf_mlp_forward_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

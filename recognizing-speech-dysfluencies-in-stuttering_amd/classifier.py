@@ -57,6 +57,84 @@ class MLPHead(nn.Module):
         return [self.classes[int(i)] for i in idx]
 
 
+class FusedMLPHead:
+    """The same scaler + MLP as ``MLPHead`` evaluated by ONE HIP kernel behind the C ABI (``dysf_mlp_*``): rows in,
+    logits / probabilities / arg-max out.  For batches that live on the GPU the eager module's seven small launches
+    cost more than its arithmetic; this is the head bench.py and the fused pipeline use."""
+
+    def __init__(self, mean, scale, weights: Sequence[np.ndarray], biases: Sequence[np.ndarray], classes=None,
+                 device: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.device = device
+        ws = [np.ascontiguousarray(w, np.float64) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float64) for b in biases]
+        dims = np.array([ws[0].shape[0]] + [w.shape[1] for w in ws], np.int32)
+        for i, w in enumerate(ws):
+            if w.shape != (dims[i], dims[i + 1]) or bs[i].shape != (dims[i + 1],):
+                raise ValueError("layer shapes do not chain")
+        self.n_features_in_, self.n_outputs = int(dims[0]), int(dims[-1])
+        self.classes = None if classes is None else [str(c) for c in classes]
+        mean = np.ascontiguousarray(mean, np.float64)
+        scale = np.ascontiguousarray(scale, np.float64)
+        wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.dysf_mlp_create(device, len(ws), dims.ctypes.data_as(ctypes.c_void_p), wp, bp,
+                               mean.ctypes.data_as(ctypes.c_void_p), scale.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.byref(self._h))
+        if rc != 0:
+            raise _lib.DysfError(f"dysf_mlp_create failed ({rc}): {L.dysf_mlp_last_error().decode()}")
+
+    @classmethod
+    def from_npz(cls, path: str, device: int = 0) -> "FusedMLPHead":
+        z = np.load(path, allow_pickle=False)
+        return cls(z["mean"], z["scale"], [z["W1"], z["W2"], z["W3"]], [z["b1"], z["b2"], z["b3"]],
+                   classes=z["classes"], device=device)
+
+    def _run(self, x: torch.Tensor, logits=True, proba=False, pred=False):
+        import ctypes
+        if x.shape[-1] != self.n_features_in_:  # the guard of main1.py:976-981
+            raise ValueError(f"Feature mismatch! Expected {self.n_features_in_}, got {x.shape[-1]}.")
+        x = x.to(torch.float32).contiguous()
+        assert x.is_cuda
+        n = x.shape[0]
+        mk = lambda on, dt, *s: torch.empty(s, dtype=dt, device=x.device) if on else None  # noqa: E731
+        lo, pr, pd = mk(logits, torch.float32, n, self.n_outputs), mk(proba, torch.float32, n, self.n_outputs), mk(pred, torch.int32, n)
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        L = self._lib.lib()
+        rc = L.dysf_mlp_forward_dev(self._h, ptr(x), n, ptr(lo), ptr(pr), ptr(pd),
+                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.DysfError(f"dysf_mlp_forward_dev failed ({rc}): {L.dysf_mlp_last_error().decode()}")
+        return lo, pr, pd
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x)[0]
+
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, logits=False, proba=True)[1]
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, logits=False, pred=True)[2].to(torch.int64)
+
+    def inverse_transform(self, idx) -> list:
+        return [self.classes[int(i)] for i in idx]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lib().dysf_mlp_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RandomForestHead:
     """scaler.transform + RandomForestClassifier.predict / predict_proba (main1.py:987-989, model of pipeline1.py:496)
     on the GPU: a HIP tree-walk kernel behind the C ABI (``dysf_forest_*``).  Built from flat node arrays exported

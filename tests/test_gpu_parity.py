@@ -381,3 +381,22 @@ def test_soft_voting_of_the_three_heads(golden_dir):
     clear = (margin[:, -1] - margin[:, -2]) > 1e-3          # rows whose winner is not within the MLP's float32 noise
     assert np.array_equal(vote.predict(x).cpu().numpy()[clear], want.argmax(1)[clear])
     assert clear.mean() > 0.95
+
+
+def test_fused_mlp_head_matches_fixture_and_eager_head(golden_dir):
+    """The one-kernel MLP head (dysf_mlp_*) against scikit-learn's outputs for the re-fitted MLP of pipeline1.py:497
+    (arg-max exact, probabilities 1e-4) and against the eager torch head on random rows (logits 1e-4 relative)."""
+    from rsd_amd.classifier import FusedMLPHead, MLPHead
+    path = os.path.join(golden_dir, "classifier_after.npz")
+    z = np.load(path)
+    fused, eager = FusedMLPHead.from_npz(path), MLPHead.from_npz(path).cuda()
+    x = torch.from_numpy(z["X"]).cuda()
+    assert np.array_equal(fused.predict(x).cpu().numpy(), z["expected_pred"])
+    assert np.abs(fused.predict_proba(x).cpu().numpy() - z["expected_proba"]).max() <= 1e-4
+    lg, le = fused(x).cpu().numpy(), eager(x).cpu().numpy()
+    assert np.abs(lg - le).max() <= 1e-4 * max(1.0, np.abs(le).max())
+    for n in (1, 7, 8, 9):  # ragged tails of the 8-row workgroups
+        assert np.array_equal(fused.predict(x[:n]).cpu().numpy(), z["expected_pred"][:n])
+    with pytest.raises(ValueError):
+        fused.predict(torch.zeros(1, 148).cuda())
+    fused.close()
