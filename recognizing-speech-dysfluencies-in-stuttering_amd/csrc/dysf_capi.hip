@@ -64,6 +64,8 @@ struct DysfHandle {
   hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* dbg_stamps = nullptr;  // DYSF_STAMP diagnostic builds
   DevBuf st_pcm, st_off, st_pooled, st_frames, st_status, st_tuning;
+  bool ws_clean = false;         // ws_small is known to be all zero once the work queued on ws_stream has run
+  hipStream_t ws_stream = nullptr;
   DevBuf d_mel_sched, d_mel_spack;  // kernel A's per-wave mel schedule and the taps laid out in its order
   int mel_slots = 0;
 };
@@ -329,6 +331,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8;
   const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(h->ws_budget / per_clip)));
   if (int rc = h->ws_logmel.reserve((size_t)sub * a.ws_logmel_stride * 4)) return rc;
+  if ((size_t)sub * 12 > h->ws_small.cap) h->ws_clean = false;
   if (int rc = h->ws_small.reserve((size_t)sub * 12)) return rc;
   if (p.chroma) {
     if (int rc = h->ws_peak_mag.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
@@ -355,12 +358,17 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.ws_clipmax = (unsigned*)h->ws_small.p;
     a.ws_flags = (int*)h->ws_small.p + sub;
     a.ws_peak_cnt = (int*)h->ws_small.p + 2 * sub;
-    HIPCHK(hipMemsetAsync(h->ws_small.p, 0, (size_t)sub * 12, stream));
+    // presets without chroma leave these words zero themselves (kernel B, after reading them): the memset node is
+    // only needed the first time, after a reallocation, a failed launch or a change of stream
+    a.self_clean = p.chroma ? 0 : 1;
+    if (!(a.self_clean && h->ws_clean && h->ws_stream == stream)) HIPCHK(hipMemsetAsync(h->ws_small.p, 0, h->ws_small.cap, stream));
+    h->ws_clean = false;
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
     HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
     if (h->timing) HIPCHK(hipEventRecord(h->tev[1], stream));
     HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
+    h->ws_clean = a.self_clean != 0; h->ws_stream = stream;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[2], stream));
     if (p.chroma) {
       a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;

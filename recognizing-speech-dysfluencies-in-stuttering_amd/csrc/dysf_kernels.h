@@ -49,6 +49,7 @@ struct KArgs {
   long long ws_logmel_stride;  // floats per clip
   int lm_stride;               // floats per log-mel row = n_mels rounded up to 16
   unsigned* ws_clipmax;        // [clip] order-preserving encoding of the clip's log-mel maximum (atomicMax)
+  int self_clean;           // kernel B zeroes ws_clipmax / ws_flags after reading them (presets without chroma)
   int* ws_flags;               // [clip] 1: non-finite sample seen
   int* ws_peak_cnt;            // [clip] piptrack peaks appended so far
   float* ws_peak_mag;

@@ -587,6 +587,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     if (prow) for (int i = tid; i < a.pooled_dim; i += NT) prow[i] = 0.f;
     if (frow) for (long long i = tid; i < 3LL * C * a.frame_stride; i += NT) frow[i] = 0.f;
     if (tid == 0 && a.tuning) a.tuning[clip] = 50;
+    if (a.self_clean) {  // leave the clip's workspace words zero for the next launch (every thread has read them)
+      __syncthreads();
+      if (tid == 0) { a.ws_clipmax[clip] = 0u; a.ws_flags[clip] = 0; }
+    }
     return;
   }
   if (tid == 0 && a.tuning && !a.chroma) a.tuning[clip] = 50;
@@ -628,6 +632,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   STAMP(8);  // setup
   for (int t0 = 0; t0 < T; t0 += CH) {
     __syncthreads();
+    // every thread has read the clip's maximum and flag by now: zero them for the next launch (no memset node then)
+    if (a.self_clean && t0 == 0 && tid == 0) { a.ws_clipmax[clip] = 0u; a.ws_flags[clip] = 0; }
     STAMP(9);  // barrier
     // a wave whose 16 columns all lie past the last frame the delta filters can reach has nothing to compute
     // (only in a clip's last chunk; wave-uniform)

@@ -400,3 +400,21 @@ def test_fused_mlp_head_matches_fixture_and_eager_head(golden_dir):
     with pytest.raises(ValueError):
         fused.predict(torch.zeros(1, 148).cuda())
     fused.close()
+
+
+def test_workspace_is_clean_after_rejected_clips(ex512):
+    """Presets without chroma skip the per-launch workspace memset: the MFCC kernel zeroes the clip maximum and the
+    non-finite flag after reading them.  A launch with rejected clips must leave nothing behind for the next one."""
+    good = [O.pcm16_to_float(synth_clip(i, n=16000)) for i in range(4)]
+    want = ex512.extract_batch(good)
+    assert (want["status"] == 0).all()
+    bad = [g.copy() for g in good]
+    bad[1][100] = np.nan
+    bad[2] = bad[2][:300]            # too short
+    bad[3] = np.zeros(0, np.float32)  # empty
+    res = ex512.extract_batch(bad)
+    assert list(res["status"]) == [rsd_amd._lib.DYSF_OK, rsd_amd._lib.DYSF_NONFINITE, rsd_amd._lib.DYSF_TOO_SHORT, rsd_amd._lib.DYSF_EMPTY]
+    assert not res["pooled"][1:].any()
+    again = ex512.extract_batch(good)
+    assert (again["status"] == 0).all()
+    assert np.array_equal(again["pooled"], want["pooled"])

@@ -11,7 +11,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dysf_" in r["Kernel_Name"]:
+        if "dysf::" in r["Kernel_Name"]:
             k = r["Kernel_Name"].split("dysf::")[1].split("<")[0]
             a = agg[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for (k, c), (v, n) in sorted(agg.items()):
