@@ -190,6 +190,26 @@ void    dysf_mlp_destroy(DysfMlp* m);
 int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_logits, float* d_proba,
                              int32_t* d_pred, void* stream);
 
+/*
+ * Rational sample-rate conversion: the resampling half of librosa.load(path, sr=16000),
+ * pipeline1.py:100-106, for batches resident on the device.  Polyphase FIR as scipy.signal.resample_poly defines it:
+ * out[n] = sum_k taps[(n + n_pre_remove)*down - k*up] * x[k], zero extension, len(out) = ceil(len(x)*up/down).
+ * taps: float64, front-padded (rsd_amd/resample.py: design_taps builds resample_poly's default Kaiser(5.0) filter).
+ *   d_pcm / pcm_type / d_in_offsets  as for dysf_extract_batch_dev (offsets are a DEVICE array here)
+ *   d_out          float32 samples of all clips back to back;  d_out_offsets [n_clips+1] int64 (device) with
+ *                  out_offsets[i+1] - out_offsets[i] = dysf_resampler_out_len(len_i)
+ *   max_out_len    an upper bound on any single clip's output length (sizes the launch)
+ */
+typedef struct DysfResampler DysfResampler;
+const char* dysf_resampler_last_error(void);
+int32_t dysf_resampler_create(int32_t device, int32_t up, int32_t down, const double* taps, int32_t n_taps,
+                              int32_t n_pre_remove, DysfResampler** out);
+void    dysf_resampler_destroy(DysfResampler* r);
+int64_t dysf_resampler_out_len(const DysfResampler* r, int64_t n_in);
+int32_t dysf_resample_batch_dev(DysfResampler* r, const void* d_pcm, int32_t pcm_type, const int64_t* d_in_offsets,
+                                int32_t n_clips, float* d_out, const int64_t* d_out_offsets, int64_t max_out_len,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

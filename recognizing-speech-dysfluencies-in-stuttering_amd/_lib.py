@@ -20,6 +20,8 @@ SYMBOLS = (
     "dysf_forest_last_error", "dysf_forest_create", "dysf_forest_destroy", "dysf_forest_predict_dev",
     "dysf_svc_last_error", "dysf_svc_create", "dysf_svc_destroy", "dysf_svc_predict_dev",
     "dysf_mlp_last_error", "dysf_mlp_create", "dysf_mlp_destroy", "dysf_mlp_forward_dev",
+    "dysf_resampler_last_error", "dysf_resampler_create", "dysf_resampler_destroy", "dysf_resampler_out_len",
+    "dysf_resample_batch_dev",
 )
 
 
@@ -90,6 +92,13 @@ def lib():
     L.dysf_mlp_destroy.argtypes = [vp]
     L.dysf_mlp_destroy.restype = None
     L.dysf_mlp_forward_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.dysf_resampler_last_error.restype = ctypes.c_char_p
+    L.dysf_resampler_create.argtypes = [i32, i32, i32, vp, i32, i32, ctypes.POINTER(vp)]
+    L.dysf_resampler_destroy.argtypes = [vp]
+    L.dysf_resampler_destroy.restype = None
+    L.dysf_resampler_out_len.argtypes = [vp, i64]
+    L.dysf_resampler_out_len.restype = i64
+    L.dysf_resample_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i64, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

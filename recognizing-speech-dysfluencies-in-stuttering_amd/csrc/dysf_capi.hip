@@ -312,7 +312,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int tile_a = ((fpi_a - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 2 * a.peak_tile_cap + 3) & ~3;
   const int lds_a_region = 0, lds_a_pcm = nw_a * rstride, lds_a_misc = lds_a_pcm + tile_a, lds_a_tables = lds_a_misc + misc_a;
-  const size_t lds_a = (size_t)(lds_a_tables + tables) * 4;
+  size_t lds_a = (size_t)(lds_a_tables + tables) * 4;
+  if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
   if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
 
   // ---- kernel C geometry (chroma): 512 threads, one workgroup per clip

@@ -185,10 +185,23 @@ def get_extractor(params: FeatureParams = REFERENCE_149, device: int = 0) -> Fea
     return _extractors[key]
 
 
+_RESAMPLERS = {}
+
+
+def _resampler(sr_in: int, sr_out: int):
+    from .resample import Resampler
+    key = (sr_in, sr_out)
+    if key not in _RESAMPLERS:
+        _RESAMPLERS[key] = Resampler(sr_in, sr_out, 0)
+    return _RESAMPLERS[key]
+
+
 def load_audio(path: str, sr: int = TARGET_SR):
-    """pipeline1.py:100-106 for the files the path is pinned on: mono PCM_16 WAV already at ``sr``.
-    Returns (float32 y, sr) or (None, None) on failure, like the reference.  Decoding other containers and
-    resampling are upstream of this path."""
+    """pipeline1.py:100-106 for mono PCM_16 WAV files.  A file already at ``sr`` (the case parity is pinned on) is
+    returned as ``int16 / 32768``; a file at another rate is converted on the GPU by ``rsd_amd.resample.Resampler``
+    (polyphase, scipy.signal.resample_poly's filter -- librosa would use soxr here, so these samples are not
+    bit-comparable with the reference's).  Returns (float32 y, sr) or (None, None) on failure, like the
+    reference.  Decoding other containers is upstream of this path."""
     try:
         with open(path, "rb") as f:
             blob = f.read()
@@ -207,9 +220,9 @@ def load_audio(path: str, sr: int = TARGET_SR):
         tag, channels, file_sr, _, _, bits = fmt
         if tag != 1 or channels != 1 or bits != 16:
             raise ValueError("only mono PCM_16 is supported on this path")
-        if file_sr != sr:
-            raise ValueError(f"file is at {file_sr} Hz; resampling to {sr} Hz is out of scope")
         pcm = np.frombuffer(data[: len(data) // 2 * 2], dtype="<i2")
+        if file_sr != sr:
+            return _resampler(int(file_sr), int(sr)).resample(pcm), int(sr)
         return (pcm.astype(np.float32) / np.float32(32768.0)), int(sr)
     except Exception as e:  # same convention as the reference
         logging.error(f"load_audio fail {path}: {e}")

@@ -418,3 +418,39 @@ def test_workspace_is_clean_after_rejected_clips(ex512):
     again = ex512.extract_batch(good)
     assert (again["status"] == 0).all()
     assert np.array_equal(again["pooled"], want["pooled"])
+
+
+def test_resampler_matches_scipy_resample_poly(tmp_path):
+    """22.05 kHz -> 16 kHz on the GPU against scipy.signal.resample_poly (float64) on the same samples:
+    float32 rounding only (2e-7 of full scale), exact output lengths, ragged batch, int16 and float32 input, and
+    load_audio() of a 22.05 kHz WAV."""
+    from rsd_amd.resample import Resampler
+    rs = Resampler(22050, 16000, 0)
+    rng = np.random.default_rng(5)
+    lens = [66150, 22050, 1, 0, 4410, 100001]
+    clips = [np.clip(rng.standard_normal(n) * 6000, -32768, 32767).astype(np.int16) for n in lens]
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+    out, out_off = rs.resample_batch_device(pcm, off, max_samples=max(lens))
+    out, out_off = out.cpu().numpy(), out_off.cpu().numpy()
+    for i, c in enumerate(clips):
+        want = O.resample_poly_ref(c, 22050, 16000) if len(c) else np.zeros(0, np.float32)
+        got = out[out_off[i]:out_off[i + 1]]
+        assert len(got) == len(want) == rs.out_len(len(c))
+        if len(c):
+            assert np.abs(got - want).max() <= 2e-7, (i, float(np.abs(got - want).max()))
+    f32 = (clips[0].astype(np.float32) / 32768.0)
+    assert np.array_equal(rs.resample(f32), rs.resample(clips[0]))
+    # a 22.05 kHz PCM_16 WAV through load_audio(sr=16000): same samples, then the feature path accepts them
+    import struct
+    path = str(tmp_path / "tone22k.wav")
+    t = np.arange(22050 * 2) / 22050.0
+    y = (0.4 * np.sin(2 * np.pi * 440.0 * t) * 32767).astype(np.int16)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + 2 * len(y)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 22050, 44100, 2, 16))
+        f.write(b"data" + struct.pack("<I", 2 * len(y)) + y.tobytes())
+    got, sr = rsd_amd.load_audio(path, sr=16000)
+    assert sr == 16000 and np.abs(got - O.resample_poly_ref(y, 22050, 16000)).max() <= 2e-7
+    feats = rsd_amd.extract_audio_features(got, sr)
+    assert np.abs(feats - O.extract_audio_features(got, 16000)).max() <= 1e-4
+    rs.close()

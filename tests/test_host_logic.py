@@ -158,3 +158,19 @@ def test_forest_fixture_reproduces_reference_metrics(golden_dir):
                 node = int(z["left"][node] if xs[r, z["feature"][node]] <= z["threshold"][node] else z["right"][node])
             acc += z["value"][node]
         assert np.abs(acc / 200 - z["expected_proba"][r]).max() < 1e-12
+
+
+def test_resampler_filter_design_equals_scipy():
+    """rsd_amd.resample.design_taps (NumPy only) against the filter scipy.signal.resample_poly builds for 22.05 -> 16 kHz
+    and 44.1 -> 16 kHz (firwin + Kaiser(5.0), times up, front padding, n_pre_remove)."""
+    from scipy.signal import firwin
+    import rsd_amd.resample as R
+    for up, down in ((320, 441), (160, 441), (2, 1), (1, 3)):
+        taps, n_pre_remove = R.design_taps(up, down)
+        half_len = 10 * max(up, down)
+        h = firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", 5.0)) * up
+        n_pre_pad = down - half_len % down
+        assert len(taps) == n_pre_pad + len(h) and not taps[:n_pre_pad].any()
+        assert np.abs(taps[n_pre_pad:] - h).max() <= 1e-13 * up
+        assert n_pre_remove == (half_len + n_pre_pad) // down
+    assert R.output_length(66150, 320, 441) == 48000 and R.output_length(1, 320, 441) == 1 and R.output_length(0, 320, 441) == 0
