@@ -454,3 +454,31 @@ def test_resampler_matches_scipy_resample_poly(tmp_path):
     feats = rsd_amd.extract_audio_features(got, sr)
     assert np.abs(feats - O.extract_audio_features(got, 16000)).max() <= 1e-4
     rs.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_fft=512, hop=256, n_mels=128, n_mfcc=40, chroma=True),    # main.py:621-630, 724-736 (MFCC_N 40, N_FFT 512, HOP 256)
+    dict(n_fft=1024, hop=256, n_mels=128, n_mfcc=20, chroma=True),
+    dict(n_fft=1024, hop=512, n_mels=64, n_mfcc=13, chroma=False),
+    dict(n_fft=256, hop=128, n_mels=40, n_mfcc=13, chroma=False),
+    dict(n_fft=256, hop=64, n_mels=64, n_mfcc=20, chroma=True),
+    dict(n_fft=2048, hop=512, n_mels=64, n_mfcc=40, chroma=False),
+], ids=lambda c: "fft%d_hop%d_mel%d_mfcc%d_%s" % (c["n_fft"], c["hop"], c["n_mels"], c["n_mfcc"], "chroma" if c["chroma"] else "nochroma"))
+def test_other_geometries_vs_oracle(cfg):
+    """Every FFT size the kernels are instantiated for (256 / 512 / 1024 / 2048 points), with and without the chroma
+    pass, including the parameterisation of main.py:718-736 -- pooled vectors 1e-4 against the oracle, tuning exact."""
+    gp, op = rsd_amd.FeatureParams(**cfg), O.FeatureParams(**cfg)
+    ex = rsd_amd.FeatureExtractor(gp, 0)
+    clips = [synth_clip(i, n=n) for i, n in ((1, 16000), (2, 9000), (3, 23456), (64, 12000), (7, 40000))]
+    res = ex.extract_batch(clips, tuning=cfg["chroma"])
+    assert (res["status"] == 0).all()
+    for k, y in enumerate(clips):
+        yf = O.pcm16_to_float(y)
+        want = O.extract_audio_features(yf, 16000, op)
+        d = np.abs(res["pooled"][k] - want)
+        assert d[: 6 * cfg["n_mfcc"]].max() <= 1e-4, (k, float(d.max()), int(d.argmax()))
+        if cfg["chroma"]:
+            idx = O.estimate_tuning(O.stft_power(yf, op), op)[1]["index"]
+            assert res["tuning"][k] == idx, (k, int(res["tuning"][k]), idx)
+            assert d[6 * cfg["n_mfcc"]:].max() <= 1e-4, (k, "chroma", float(d[6 * cfg["n_mfcc"]:].max()))
+    ex.close()
