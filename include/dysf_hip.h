@@ -60,11 +60,15 @@ typedef struct DysfParams {
   float   amin;        /* power_to_db floor (1e-10)                                            */
   int32_t delta_width; /* must be 9 (librosa default; the only width the reference uses)       */
   int32_t chroma;      /* 1: append chroma_stft mean/std (12 + 12) to the pooled row           */
-  int32_t reserved[5];
+  int32_t rich;        /* 1: append main.py:738-754's descriptors to the pooled row: spectral-contrast mean (7) */
+                       /*    and std (7), mean zero-crossing rate, mean RMS, mean spectral centroid (17 floats); */
+                       /*    2048 must be a whole number of hops (frame_length of librosa's zcr / rms)            */
+  int32_t reserved[4];
 } DysfParams;
 
 #define DYSF_PRESET_REFERENCE_149 0 /* pipeline1.py / main1.py: 2048/512/128 mel/20 mfcc + chroma      */
 #define DYSF_PRESET_BENCH_512     1 /* BASELINE.json configs[1]: 512/160/64 mel/40 mfcc, no chroma     */
+#define DYSF_PRESET_MAIN_286      2 /* main.py:621-630, 718-763: 512/256/128 mel/40 mfcc + chroma + rich  */
 
 typedef struct DysfHandle DysfHandle;
 

@@ -6,13 +6,13 @@ Python host code over a thin C-ABI HIP library (``libdysf_hip.so``, ``include/dy
 device-resident entry points need it."""
 from . import _lib
 from ._lib import DysfError
-from .params import BENCH_512, REFERENCE_149, TARGET_SR, FeatureParams
+from .params import BENCH_512, MAIN_286, REFERENCE_149, TARGET_SR, FeatureParams
 from .features import (CACHE_DIR, FeatureExtractor, HostTables, cached_extract_features, cached_path,
                        extract_audio_features, extract_features, extract_text_features, get_extractor,
                        load_audio, load_cache, repetition_stats_from_text, save_cache)
 
 __all__ = [
-    "DysfError", "FeatureParams", "REFERENCE_149", "BENCH_512", "TARGET_SR", "CACHE_DIR", "FeatureExtractor",
+    "DysfError", "FeatureParams", "REFERENCE_149", "BENCH_512", "MAIN_286", "TARGET_SR", "CACHE_DIR", "FeatureExtractor",
     "HostTables", "get_extractor", "load_audio", "save_cache", "load_cache", "cached_path",
     "extract_audio_features", "extract_text_features", "extract_features", "cached_extract_features",
     "repetition_stats_from_text",

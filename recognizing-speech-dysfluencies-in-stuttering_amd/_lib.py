@@ -30,7 +30,8 @@ class DysfParams(ctypes.Structure):
         ("sr", ctypes.c_int32), ("n_fft", ctypes.c_int32), ("hop", ctypes.c_int32),
         ("n_mels", ctypes.c_int32), ("n_mfcc", ctypes.c_int32),
         ("fmin", ctypes.c_float), ("fmax", ctypes.c_float), ("top_db", ctypes.c_float), ("amin", ctypes.c_float),
-        ("delta_width", ctypes.c_int32), ("chroma", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+        ("delta_width", ctypes.c_int32), ("chroma", ctypes.c_int32), ("rich", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

@@ -53,9 +53,11 @@ struct DysfHandle {
   double* d_dct_pack = nullptr;
   float* d_dct_pack32 = nullptr;
   double* d_dct_rowsum = nullptr;
+  int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   int* d_mel_meta = nullptr;
   // workspace / staging
+  DevBuf ws_rich;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
@@ -91,6 +93,8 @@ int32_t dysf_params_preset(int32_t preset, DysfParams* p) {
     p->n_fft = 2048; p->hop = 512; p->n_mels = 128; p->n_mfcc = 20; p->chroma = 1;
   } else if (preset == DYSF_PRESET_BENCH_512) {
     p->n_fft = 512; p->hop = 160; p->n_mels = 64; p->n_mfcc = 40; p->chroma = 0;
+  } else if (preset == DYSF_PRESET_MAIN_286) {
+    p->n_fft = 512; p->hop = 256; p->n_mels = 128; p->n_mfcc = 40; p->chroma = 1; p->rich = 1;
   } else {
     return fail(DYSF_E_INVALID, "unknown preset");
   }
@@ -128,6 +132,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     rc |= upload(&h->d_dct_pack, h->t.dct_pack64);
     rc |= upload(&h->d_dct_pack32, h->t.dct_pack32);
     rc |= upload(&h->d_dct_rowsum, h->t.dct_rowsum);
+    rc |= upload(&h->d_rich_tab, h->t.rich_tab);
     rc |= upload(&h->d_chroma_pack, h->t.chroma_pack);
     if (rc) { dysf_destroy(h); return DYSF_E_HIP; }
   }
@@ -140,9 +145,9 @@ void dysf_destroy(DysfHandle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
-    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum);
+    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
-    h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
+    h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
     for (int i = 0; i < 4; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
@@ -150,7 +155,9 @@ void dysf_destroy(DysfHandle* h) {
   delete h;
 }
 
-int32_t dysf_pooled_dim(const DysfHandle* h) { return h ? 6 * h->t.p.n_mfcc + (h->t.p.chroma ? 2 * kChroma : 0) : DYSF_E_INVALID; }
+int32_t dysf_pooled_dim(const DysfHandle* h) {
+  return h ? 6 * h->t.p.n_mfcc + (h->t.p.chroma ? 2 * kChroma : 0) + (h->t.p.rich ? kRichDim : 0) : DYSF_E_INVALID;
+}
 int32_t dysf_frame_rows(const DysfHandle* h) { return h ? 3 * h->t.p.n_mfcc : DYSF_E_INVALID; }
 int64_t dysf_num_frames(const DysfHandle* h, int64_t n_samples) {
   if (!h || n_samples < 0) return DYSF_E_INVALID;
@@ -322,14 +329,17 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int misc_c = (128 + nw_c * cb_c * 256 + 16 * cb_c * 16 + 3) & ~3;
   const int lds_c_pcm = nw_c * rstride, lds_c_misc = lds_c_pcm + tile_c, lds_c_tables = lds_c_misc + misc_c;
   const size_t lds_c = (size_t)(lds_c_tables + tables) * 4;
-  if (p.chroma && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+  if ((p.chroma || p.rich) && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+  if (p.rich && (size_t)nw_c * rstride * 4 < (size_t)kRichSegBytes) return fail(DYSF_E_INVALID, "LDS regions too small for the rich preset");
 
   // ---- kernel B LDS: frame-0 features, float64 DCT operands, MFCC chunk (the final reduction reuses the last two)
   const int nd = t.dct_pack.row_blocks * t.dct_groups * 256;
   const size_t lds_b = (size_t)(kMfccHead + std::max(2 * nd + t.cpad * kMfccCstr, 8 * (18 * 65 + 3) + 2 * 8 * 18)) * 4;
 
   // ---- per-clip workspace; very large batches run as several sub-batches that reuse it
-  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8;
+  a.ws_rich_stride = p.rich ? t_max : 0;
+  a.rich_offset = 6 * p.n_mfcc + (p.chroma ? 2 * kChroma : 0); a.rich_fl = kRichFrameLength; a.rich_tab = h->d_rich_tab;
+  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4;
   const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(h->ws_budget / per_clip)));
   if (int rc = h->ws_logmel.reserve((size_t)sub * a.ws_logmel_stride * 4)) return rc;
   if ((size_t)sub * 12 > h->ws_small.cap) h->ws_clean = false;
@@ -338,6 +348,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     if (int rc = h->ws_peak_mag.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
     if (int rc = h->ws_peak_bin.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
   }
+  if (p.rich) { if (int rc = h->ws_rich.reserve((size_t)sub * a.ws_rich_stride * 14 * 4)) return rc; }
+  a.ws_rich = (float*)h->ws_rich.p;
   a.ws_logmel = (float*)h->ws_logmel.p;
   a.ws_peak_mag = (float*)h->ws_peak_mag.p;
   a.ws_peak_bin = (int*)h->ws_peak_bin.p;
@@ -361,7 +373,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.ws_peak_cnt = (int*)h->ws_small.p + 2 * sub;
     // presets without chroma leave these words zero themselves (kernel B, after reading them): the memset node is
     // only needed the first time, after a reallocation, a failed launch or a change of stream
-    a.self_clean = p.chroma ? 0 : 1;
+    a.self_clean = (p.chroma || p.rich) ? 0 : 1;  // (kernels C and D read the flag after kernel B)
     if (!(a.self_clean && h->ws_clean && h->ws_stream == stream)) HIPCHK(hipMemsetAsync(h->ws_small.p, 0, h->ws_small.cap, stream));
     h->ws_clean = false;
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
@@ -374,6 +386,10 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     if (p.chroma) {
       a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
       HIPCHK(launch_chroma(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
+    }
+    if (p.rich) {
+      a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
+      HIPCHK(launch_rich(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
     }
     if (h->timing) HIPCHK(hipEventRecord(h->tev[3], stream));
   }

@@ -43,6 +43,12 @@ struct KArgs {
   int dct_rb, dct_groups;  // row blocks of 16 coefficients, K groups of 16 mels
   const float* chroma_pack;
   int chroma_steps;
+  // rich presets (kernel D)
+  int rich_offset;          // first float of the rich descriptors in a pooled row
+  int rich_fl;              // frame length of zero_crossing_rate / rms (2048)
+  const int* rich_tab;      // [7][3] contrast bands: first bin, end bin, bins averaged at each end
+  float* ws_rich;           // [clip][14][ws_rich_stride] per-frame peak (7 rows) and valley (7 rows) magnitudes
+  long long ws_rich_stride;
   int pip_kmin, pip_kmax;
   // per-clip global workspace
   float* ws_logmel;            // [clip][T_max][lm_stride] log-mel (dB, un-clamped), frame-major
@@ -63,6 +69,9 @@ struct KArgs {
 constexpr int kMelMaxSeg = 4;
 constexpr int kMelSchedStride = 40;  // ints per wave: kMelMaxSeg x {rb, cb, kbeg, nsteps, poff, kind, slot, nparts}, nseg at [32]
 constexpr int kStftMiscBase = 32 + 8 * kMelSchedStride;  // kernel A misc area before the split-K slots
+constexpr int kRichDim = 17;                             // rich presets: 7 + 7 contrast statistics, zcr, rms, centroid
+constexpr int kRichFrameLength = 2048;                   // librosa's default frame_length of zero_crossing_rate / rms
+constexpr int kRichSegBytes = 1024 * 16;                 // kernel D: LDS taken from the regions by its segment sums
 constexpr int kMfccCstr = 132;                           // kernel B: LDS row stride of the MFCC chunk (128 columns)
 constexpr int kMfccHead = 144;                           // kernel B: frame-0 features ahead of the DCT operands
 
@@ -72,5 +81,6 @@ constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_rich(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 
 }  // namespace dysf

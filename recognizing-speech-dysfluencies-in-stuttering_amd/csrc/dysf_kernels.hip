@@ -964,6 +964,207 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   }
 }
 
+// =============================================================================================
+// Kernel D (rich presets, main.py:738-754): spectral contrast mean / std (7 + 7), mean zero-crossing rate, mean RMS,
+// mean spectral centroid.  One workgroup per clip: a third STFT pass (librosa recomputes the spectrogram for every
+// descriptor too) in which the lane group that transformed a frame also reduces it -- centroid sums and, per octave
+// band, the mean of the n_avg smallest / largest magnitudes by repeated (value, bin) min / max extraction -- then the
+// two clip-global top_db clamps and the statistics, then the time-domain descriptors from hop-sized segment sums
+// (frame_length 2048 is a whole number of hops; checked on the host).
+constexpr int kRichBands = 7;
+constexpr int kRichSegCap = 1024;  // hop segments held in LDS per pass of the time-domain part
+
+__device__ __forceinline__ double block_sum(double v, double* scratch, int tid, int nw) {  // scratch: nw doubles
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t += scratch[w];
+  return t;
+}
+
+template <int NC, int PCM, int NT>
+__global__ __launch_bounds__(NT, 2) void dysf_rich_kernel(const KArgs a) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L, FPW = G::FPW;
+  constexpr int NW = NT / 64;
+  constexpr int FPI = FPW * NW;
+  constexpr int EPG = PcmStage<PCM>::EPG;
+  extern __shared__ __align__(16) float lds[];
+  float* regions = lds + a.lds_region;
+  float* tile = lds + a.lds_pcm;
+  double* red = (double*)(lds + a.lds_misc);  // [16] block-reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane / L;
+  const int ls = (FPW == 4) ? ((lane + ((q & 1) ? L / 2 : 0)) % L) : lane % L;  // FFT role (see kernel A)
+  const int li = lane % L;                                                      // role in the per-frame reductions
+  const int clip = blockIdx.x;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  if (n <= 0 || T < 9 || a.ws_flags[clip] || !a.pooled) return;  // rejected clip: kernel B already wrote the zero row
+  float* wregion = regions + wave * a.rstride;
+  float* xb = wregion + q * G::XSTRIDE;
+  float* srow = wregion + q * a.kpad;
+  FftTabs tb;
+  load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
+  float* prow = a.pooled + (size_t)clip * a.pooled_dim + a.rich_offset;
+  float* ws = a.ws_rich + (size_t)clip * 2 * kRichBands * a.ws_rich_stride;  // rows 0..6 peak, 7..13 valley, [T] each
+  const int* tab = a.rich_tab;                                                // [band][3] = first bin, end bin, n_avg
+  const double hz_per_bin = (double)a.sr / (double)(2 * NC);
+  double cent_acc = 0.0;
+
+  const int ntiles = (T + FPI - 1) / FPI;
+  const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
+  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
+  const int n32 = (int)n, off_lo = (int)(off & (EPG - 1));
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int f0 = ti * FPI;
+    const int cs0 = f0 * a.hop - NC;
+    const int cr0 = pcm_tile_origin<PCM>(off_lo, cs0);
+    __syncthreads();  // every wave is done with the previous PCM tile
+    {
+      PcmStage<PCM> stage;
+      const int cng = (cs0 + tile_samples - cr0 + EPG - 1) / EPG;
+      pcm_prefetch<PCM, NT>(stage, pbase, n32, cr0, cng);
+      pcm_commit<PCM, NT>(stage, tile, pbase, n32, cr0, cng);
+    }
+    __syncthreads();
+    wave_frame_power<NC>(tile + (cs0 - cr0), (wave * FPW + q) * a.hop, xb, srow, ls, tb, a);
+    // the row belongs to this lane group: no workgroup barrier needed before reading it back
+    const int t = f0 + wave * FPW + q;
+    const bool valid = t < T;
+    {  // spectral centroid: sum_k f_k |X_k| / sum_k |X_k|
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = li; k <= NC; k += L) {
+        const float m = __fsqrt_rn(srow[k]);
+        s0 += (double)m; s1 += (double)m * (double)k;
+      }
+#pragma unroll
+      for (int o = L / 2; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+      if (valid && li == 0) cent_acc += (s0 < 2.2250738585072014e-308) ? 0.0 : s1 * hz_per_bin / s0;
+    }
+    for (int b = 0; b < kRichBands; ++b) {
+      const int lo = tab[3 * b], hi = tab[3 * b + 1], na = tab[3 * b + 2];
+      float lv = -INFINITY, hv = INFINITY;  // last extracted (value, bin) from the bottom / from the top
+      int lk = -1, hk = 0x7fffffff;
+      float sum_lo = 0.f, sum_hi = 0.f;
+      for (int pass = 0; pass < na; ++pass) {
+        float bv = INFINITY, tv = -INFINITY;
+        int bk = 0x7fffffff, tk = -1;
+        for (int k = lo + li; k < hi; k += L) {
+          const float m = __fsqrt_rn(srow[k]);
+          if ((m > lv || (m == lv && k > lk)) && (m < bv || (m == bv && k < bk))) { bv = m; bk = k; }
+          if ((m < hv || (m == hv && k < hk)) && (m > tv || (m == tv && k > tk))) { tv = m; tk = k; }
+        }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o); const int ok = __shfl_xor(bk, o);
+          if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+          const float pv = __shfl_xor(tv, o); const int pk = __shfl_xor(tk, o);
+          if (pv > tv || (pv == tv && pk > tk)) { tv = pv; tk = pk; }
+        }
+        sum_lo += bv; sum_hi += tv;
+        lv = bv; lk = bk; hv = tv; hk = tk;
+      }
+      if (valid && li == 0) {
+        ws[(size_t)b * a.ws_rich_stride + t] = sum_hi / (float)na;
+        ws[(size_t)(kRichBands + b) * a.ws_rich_stride + t] = sum_lo / (float)na;
+      }
+    }
+  }
+  __syncthreads();  // all peak / valley rows of the clip are written (and visible to the workgroup)
+
+  // ---- power_to_db(peak) - power_to_db(valley), each clamped 80 dB below its own clip-global maximum; statistics
+  {
+    double mp = -INFINITY, mv = -INFINITY;
+    for (int i = tid; i < kRichBands * T; i += NT) {
+      const int b = i / T, t = i % T;
+      mp = fmax(mp, 10.0 * log10(fmax(1e-10, (double)ws[(size_t)b * a.ws_rich_stride + t])));
+      mv = fmax(mv, 10.0 * log10(fmax(1e-10, (double)ws[(size_t)(kRichBands + b) * a.ws_rich_stride + t])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mp = fmax(mp, __shfl_xor(mp, o)); mv = fmax(mv, __shfl_xor(mv, o)); }
+    if (lane == 0) { red[wave] = mp; red[NW + wave] = mv; }
+    __syncthreads();
+    for (int w = 0; w < NW; ++w) { mp = fmax(mp, red[w]); mv = fmax(mv, red[NW + w]); }
+    __syncthreads();
+    if (wave < kRichBands) {
+      const int b = wave;
+      const float* pr = ws + (size_t)b * a.ws_rich_stride;
+      const float* vr = ws + (size_t)(kRichBands + b) * a.ws_rich_stride;
+      auto contrast = [&](int t) {
+        const double dp = fmax(10.0 * log10(fmax(1e-10, (double)pr[t])), mp - 80.0);
+        const double dv = fmax(10.0 * log10(fmax(1e-10, (double)vr[t])), mv - 80.0);
+        return dp - dv;
+      };
+      const double c0 = contrast(0);
+      double s1 = 0.0, s2 = 0.0;
+      for (int t = lane; t < T; t += 64) { const double e = contrast(t) - c0; s1 += e; s2 += e * e; }
+      s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (lane == 0) {
+        const double m1 = s1 / (double)T, var = s2 / (double)T - m1 * m1;
+        prow[b] = (float)(c0 + m1);
+        prow[kRichBands + b] = (float)sqrt(var > 0.0 ? var : 0.0);
+      }
+    }
+  }
+
+  // ---- zero-crossing rate and RMS over frames of a.rich_fl samples (edge / zero padding of rich_fl/2 at both ends)
+  double zsum = 0.0, rsum = 0.0;
+  {
+    const int FL = a.rich_fl, R = FL / a.hop, half = FL / 2;
+    double* seg_sq = (double*)regions;                 // regions are free now
+    int* seg_zc = (int*)(seg_sq + kRichSegCap);
+    int* seg_first = seg_zc + kRichSegCap;
+    auto sample = [&](long long s) -> float {          // y[s] for 0 <= s < n
+      return (PCM == DYSF_PCM_I16) ? (float)((const short*)pbase)[s] * (1.0f / 32768.0f) : ((const float*)pbase)[s];
+    };
+    const int fchunk = kRichSegCap - R + 1;            // frames per pass
+    for (int fbeg = 0; fbeg < T; fbeg += fchunk) {
+      const int nf = min(fchunk, T - fbeg), nseg = nf + R - 1;
+      __syncthreads();
+      for (int j = wave; j < nseg; j += NW) {
+        double sq = 0.0;
+        int zc = 0, first = 0;
+        for (int i = lane; i < a.hop; i += 64) {
+          const long long pi = (long long)(fbeg + j) * a.hop + i, sidx = pi - half;
+          const float yz = (sidx >= 0 && sidx < n) ? sample(sidx) : 0.f;
+          const long long c1 = sidx < 0 ? 0 : (sidx > n - 1 ? n - 1 : sidx);
+          const long long c0i = sidx - 1 < 0 ? 0 : (sidx - 1 > n - 1 ? n - 1 : sidx - 1);
+          const bool cross = (pi >= 1) && ((sample(c1) < -1e-10f) != (sample(c0i) < -1e-10f));
+          sq += (double)yz * (double)yz;
+          zc += cross ? 1 : 0;
+          if (i == 0) first = cross ? 1 : 0;
+        }
+        sq = wave_sum(sq);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) zc += __shfl_xor(zc, o);
+        first = __shfl(first, 0);
+        if (lane == 0) { seg_sq[j] = sq; seg_zc[j] = zc; seg_first[j] = first; }
+      }
+      __syncthreads();
+      for (int f = tid; f < nf; f += NT) {
+        double sq = 0.0;
+        int zc = -seg_first[f];                        // a frame's first sample has no predecessor inside the frame
+        for (int r = 0; r < R; ++r) { sq += seg_sq[f + r]; zc += seg_zc[f + r]; }
+        zsum += (double)zc / (double)FL;
+        rsum += (double)__fsqrt_rn((float)(sq / (double)FL));
+      }
+    }
+  }
+  zsum = block_sum(zsum, red, tid, NW);
+  rsum = block_sum(rsum, red, tid, NW);
+  cent_acc = block_sum(cent_acc, red, tid, NW);
+  if (tid == 0) {
+    prow[2 * kRichBands + 0] = (float)(zsum / (double)T);
+    prow[2 * kRichBands + 1] = (float)(rsum / (double)T);
+    prow[2 * kRichBands + 2] = (float)(cent_acc / (double)T);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
@@ -992,6 +1193,21 @@ template <int NC>
 static hipError_t launch_chroma_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_I16, 512>, grid, 512, lds_bytes, s, a);
   return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_F32, 512>, grid, 512, lds_bytes, s, a);
+}
+
+template <int NC>
+static hipError_t launch_rich_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_rich_kernel<NC, DYSF_PCM_I16, 512>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_rich_kernel<NC, DYSF_PCM_F32, 512>, grid, 512, lds_bytes, s, a);
+}
+hipError_t launch_rich(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  switch (n_fft) {
+    case 256: return launch_rich_nc<128>(a, pcm_type, grid, lds_bytes, s);
+    case 512: return launch_rich_nc<256>(a, pcm_type, grid, lds_bytes, s);
+    case 1024: return launch_rich_nc<512>(a, pcm_type, grid, lds_bytes, s);
+    case 2048: return launch_rich_nc<1024>(a, pcm_type, grid, lds_bytes, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {

@@ -69,6 +69,7 @@ struct HostTables {
   std::vector<float> dct_pack32;   // the float32 coefficients in the same layout
   std::vector<double> dct_rowsum;  // [16 * row blocks] float64 sum over mels of every row's float32 coefficients
   int dct_groups = 0;               // groups of 16 mels = mpad / 16
+  std::vector<int32_t> rich_tab;    // rich presets: [7][3] contrast bands (first bin, end bin, bins averaged per end)
   std::vector<float> chroma_pack;  // [100][chroma_steps*64]
   int chroma_steps = 0;
   int pip_kmin = 0, pip_kmax = 0;  // piptrack bins with 150 <= f < min(4000, sr/2)
@@ -143,6 +144,8 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   if (p.delta_width != 9) { *err = "delta_width must be 9"; return false; }
   if (p.sr < 1) { *err = "sr must be positive"; return false; }
   if (!(p.amin > 0.f)) { *err = "amin must be positive"; return false; }
+  if (p.rich && (2048 % p.hop != 0)) { *err = "rich presets need a hop that divides 2048 (frame_length of zcr / rms)"; return false; }
+  if (p.rich && 6400.0 >= 0.5 * p.sr) { *err = "rich presets need sr > 12800 Hz (spectral_contrast bands)"; return false; }
   const int n_fft = p.n_fft, sr = p.sr;
   t.n_bins = n_fft / 2 + 1;
   t.mpad = (p.n_mels + 15) / 16 * 16;
@@ -220,6 +223,25 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
               t.dct_pack32[(((size_t)rb * groups + g) * 64 + l) * 4 + s] = t.dct[(size_t)c * p.n_mels + m];
             }
           }
+  }
+  // spectral_contrast bands (librosa defaults fmin 200 Hz, 6 octave bands + the remainder, quantile 0.02): the bins
+  // that get sorted and how many are averaged at each end -- the index arithmetic of librosa.feature.spectral_contrast
+  if (p.rich) {
+    const int n_bands = 6;
+    std::vector<double> octa(n_bands + 2, 0.0);
+    for (int i = 0; i <= n_bands; ++i) octa[i + 1] = 200.0 * std::pow(2.0, (double)i);
+    for (int k = 0; k <= n_bands; ++k) {
+      int a0 = -1, b0 = -1;  // first / last bin with f_low <= freq <= f_high
+      for (int b = 0; b < t.n_bins; ++b)
+        if (fftfreqs[b] >= octa[k] && fftfreqs[b] <= octa[k + 1]) { if (a0 < 0) a0 = b; b0 = b; }
+      if (a0 < 0) { t.rich_tab.clear(); break; }  // band above Nyquist: the caller rejects the preset
+      int first = a0 - (k > 0 ? 1 : 0);
+      int last = (k == n_bands) ? t.n_bins - 1 : b0;  // inclusive end of `current_band`
+      const int n_cur = last - first + 1;
+      const int end = (k < n_bands) ? last : last + 1;  // bands below the top drop their last bin before sorting
+      const int n_avg = std::max((int)std::nearbyint(0.02 * (double)n_cur), 1);
+      t.rich_tab.push_back(first); t.rich_tab.push_back(end); t.rich_tab.push_back(n_avg);
+    }
   }
   // piptrack frequency mask
   {

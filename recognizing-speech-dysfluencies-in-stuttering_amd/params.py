@@ -25,6 +25,7 @@ class FeatureParams:
     amin: float = 1e-10
     delta_width: int = 9
     chroma: bool = True
+    rich: bool = False         # main.py:738-754: + spectral-contrast mean/std (14), mean zcr, mean rms, mean centroid
 
     @property
     def n_bins(self) -> int:
@@ -32,7 +33,7 @@ class FeatureParams:
 
     @property
     def audio_feature_len(self) -> int:       # AUDIO_FEATURE_LEN, pipeline1.py:83
-        return 6 * self.n_mfcc + (24 if self.chroma else 0)
+        return 6 * self.n_mfcc + (24 if self.chroma else 0) + (17 if self.rich else 0)
 
     @property
     def total_feature_len(self) -> int:       # TOTAL_FEATURE_LEN, pipeline1.py:86
@@ -50,8 +51,11 @@ class FeatureParams:
         c.amin = float(self.amin)
         c.delta_width = self.delta_width
         c.chroma = 1 if self.chroma else 0
+        c.rich = 1 if self.rich else 0
         return c
 
 
 REFERENCE_149 = FeatureParams()
 BENCH_512 = FeatureParams(n_fft=512, hop=160, n_mels=64, n_mfcc=40, chroma=False)
+# main.py:621-630, 718-763 (main.py:628 evaluates to 281 audio + 5 text values, not the 329 of its comment)
+MAIN_286 = FeatureParams(n_fft=512, hop=256, n_mfcc=40, chroma=True, rich=True)

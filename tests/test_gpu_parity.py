@@ -482,3 +482,35 @@ def test_other_geometries_vs_oracle(cfg):
             assert res["tuning"][k] == idx, (k, int(res["tuning"][k]), idx)
             assert d[6 * cfg["n_mfcc"]:].max() <= 1e-4, (k, "chroma", float(d[6 * cfg["n_mfcc"]:].max()))
     ex.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_fft=512, hop=256, n_mels=128, n_mfcc=40, chroma=True, rich=True),     # MAIN_286 = main.py:621-630, 718-763
+    dict(n_fft=2048, hop=512, n_mels=128, n_mfcc=20, chroma=False, rich=True),
+    dict(n_fft=1024, hop=256, n_mels=64, n_mfcc=13, chroma=True, rich=True),
+], ids=["main286", "fft2048_rich", "fft1024_rich"])
+def test_rich_descriptors_vs_oracle(cfg):
+    """spectral-contrast mean/std, mean zero-crossing rate, mean RMS and mean spectral centroid of
+    main.py:738-754 (kernel D) against the oracle's restatement of the librosa primitives (parity unpinned: the
+    reference's own output for this set is all zeros, m:753).  Tolerances: MFCC/chroma blocks 1e-4 as everywhere;
+    contrast (dB) 2e-4; zcr 1e-7; rms 1e-6; centroid (Hz, values ~1e3) 5e-3."""
+    gp, op = rsd_amd.FeatureParams(**cfg), O.FeatureParams(**cfg)
+    ex = rsd_amd.FeatureExtractor(gp, 0)
+    assert ex.pooled_dim == op.audio_feature_len
+    clips = [synth_clip(i, n=n) for i, n in ((1, 16000), (2, 9000), (3, 23456), (64, 12000), (7, 40000), (128, 30000))]
+    res = ex.extract_batch(clips)
+    assert (res["status"] == 0).all()
+    base = 6 * cfg["n_mfcc"] + (24 if cfg["chroma"] else 0)
+    for k, y in enumerate(clips):
+        yf = O.pcm16_to_float(y)
+        want = O.extract_audio_features(yf, 16000, op, strict=True)
+        got = res["pooled"][k]
+        assert np.abs(got[: 6 * cfg["n_mfcc"]] - want[: 6 * cfg["n_mfcc"]]).max() <= 1e-4
+        r, w = got[base:], want[base:]
+        assert np.abs(r[:14] - w[:14]).max() <= 2e-4, (k, "contrast", r[:14], w[:14])
+        assert abs(r[14] - w[14]) <= 1e-7, (k, "zcr", float(r[14]), float(w[14]))
+        assert abs(r[15] - w[15]) <= 1e-6, (k, "rms", float(r[15]), float(w[15]))
+        assert abs(r[16] - w[16]) <= 5e-3, (k, "centroid", float(r[16]), float(w[16]))
+    if cfg["n_fft"] == 512:
+        assert ex.pooled_dim == 281 and rsd_amd.MAIN_286 == gp
+    ex.close()
