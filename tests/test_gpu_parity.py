@@ -441,6 +441,13 @@ def test_resampler_matches_scipy_resample_poly(tmp_path):
             assert np.abs(got - want).max() <= 2e-7, (i, float(np.abs(got - want).max()))
     f32 = (clips[0].astype(np.float32) / 32768.0)
     assert np.array_equal(rs.resample(f32), rs.resample(clips[0]))
+    # other ratios take the general kernel (taps from L2): many taps per phase (44.1 -> 16 kHz), tiny up (8 -> 16 kHz)
+    for sr_in, sr_out in ((44100, 16000), (8000, 16000), (16000, 22050)):
+        r2 = Resampler(sr_in, sr_out, 0)
+        got = r2.resample(clips[4])
+        want = O.resample_poly_ref(clips[4], sr_in, sr_out)
+        assert len(got) == len(want) and np.abs(got - want).max() <= 2e-7, (sr_in, sr_out)
+        r2.close()
     # a 22.05 kHz PCM_16 WAV through load_audio(sr=16000): same samples, then the feature path accepts them
     import struct
     path = str(tmp_path / "tone22k.wav")
