@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const floa
 
 struct DysfMlp {
   int device = 0;
+  bool attr_set = false;
   MlpDev d{};
   std::vector<void*> bufs;
 };
@@ -228,6 +229,12 @@ int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_l
   if (n == 0) return 0;
   if (hipSetDevice(m->device) != hipSuccess) { g_merr = "hipSetDevice failed"; return DYSF_E_HIP; }
   const size_t lds = ((size_t)2 * kRows * m->d.width + (size_t)kTileFloats) * sizeof(float);
+  if (!m->attr_set) {  // more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute((const void*)dysf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_merr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
+    }
+    m->attr_set = true;
+  }
   hipLaunchKernelGGL(dysf_mlp_kernel, dim3((n + kRows - 1) / kRows), dim3(kThreads), lds, (hipStream_t)stream, m->d, d_x,
                      n, d_logits, d_proba, d_pred);
   const hipError_t e = hipGetLastError();
