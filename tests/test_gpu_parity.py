@@ -521,3 +521,32 @@ def test_rich_descriptors_vs_oracle(cfg):
     if cfg["n_fft"] == 512:
         assert ex.pooled_dim == 281 and rsd_amd.MAIN_286 == gp
     ex.close()
+
+
+def test_lane_executor_equals_serial_path(ex512):
+    """Batches alternating over three HIP streams / extractor handles (rsd_amd.pipeline.LaneExecutor, what bench.py runs)
+    give bit-identical features to the single-stream path, in submission order, also when batches differ."""
+    from rsd_amd.classifier import FusedMLPHead
+    from rsd_amd.pipeline import LaneExecutor
+    rng = np.random.default_rng(1)
+    dims = [ex512.pooled_dim, 16, 3]
+    head = FusedMLPHead(np.zeros(dims[0]), np.ones(dims[0]), [rng.standard_normal((dims[i], dims[i + 1])) * 0.05 for i in range(2)],
+                        [np.zeros(dims[i + 1]) for i in range(2)])
+    lanes = LaneExecutor(B512, 0, 3, head=head)
+    batches = []
+    for b in range(7):
+        clips = [synth_clip(10 * b + i, n=8000 + 997 * ((b + i) % 5)) for i in range(6)]
+        lens = [len(c) for c in clips]
+        pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+        batches.append((pcm, off, max(lens)))
+    torch.cuda.synchronize()
+    lanes.fork()
+    got = [lanes.submit(p, o, m, pooled=True, frames=True) for p, o, m in batches]
+    lanes.join()
+    torch.cuda.synchronize()
+    for (p, o, m), g in zip(batches, got):
+        want = ex512.extract_batch_device(p, o, m, pooled=True, frames=True)
+        torch.cuda.synchronize()
+        assert torch.equal(g["pooled"], want["pooled"]) and torch.equal(g["frames"], want["frames"])
+        assert torch.equal(g["logits"], head(want["pooled"]))
