@@ -10,7 +10,10 @@ A step = one pass of the hot path over one resident batch: 1024 synthetic 3 s @ 
 frame-level rows [1024, 120, 301] fp32 (the CNN input of configs[2]) and as pooled mean/std rows [1024, 240];
 then the pooled rows go through a small MLP head to per-clip logits and, for N > 1, the single collective of the
 path: an RCCL all-gather of the [1024, 3] logits.  Every rank owns its own 1024-clip shard (weak scaling); the
-PCM is already in HBM when the timed region starts.
+PCM is already in HBM when the timed region starts.  Steps are independent batches, so they are submitted round-robin to
+`--lanes` HIP streams (rsd_amd.pipeline.LaneExecutor, default 3, each lane with its own extractor handle): the STFT kernel
+of one step overlaps the MFCC kernel / head / gather of the previous one.  All lanes are joined before the closing fence;
+`--lanes 1` is the strictly serial loop.
 
 Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel (HIP-event timed on the
 launch stream) and, at N = 1, a `cpu_baseline` object (the NumPy oracle timed on the host cores on a bounded
