@@ -48,14 +48,13 @@ struct DysfHandle {
   size_t lds_limit = 163840;
   // device tables
   float* d_window_i16 = nullptr;
-  float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr, *d_mel_pack = nullptr,
+  float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr,
         *d_chroma_pack = nullptr;
   double* d_dct_pack = nullptr;
   float* d_dct_pack32 = nullptr;
   double* d_dct_rowsum = nullptr;
   int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
-  int* d_mel_meta = nullptr;
   // workspace / staging
   DevBuf ws_rich;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
@@ -127,8 +126,6 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     }
     rc |= upload(&h->d_stage_tw, h->t.stage_tw);
     rc |= upload(&h->d_post_tw, h->t.post_tw);
-    rc |= upload(&h->d_mel_pack, h->t.mel_pack.data);
-    rc |= upload(&h->d_mel_meta, h->t.mel_pack.meta);
     rc |= upload(&h->d_dct_pack, h->t.dct_pack64);
     rc |= upload(&h->d_dct_pack32, h->t.dct_pack32);
     rc |= upload(&h->d_dct_rowsum, h->t.dct_rowsum);
@@ -145,7 +142,7 @@ void dysf_destroy(DysfHandle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
-    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_mel_pack); (void)hipFree(h->d_mel_meta); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
+    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
