@@ -12,8 +12,9 @@ n = 16384
 flat = np.tile(bank.reshape(-1), n // 256)
 offsets = np.arange(n + 1, dtype=np.int64) * 48000
 ex = rsd_amd.FeatureExtractor(rsd_amd.BENCH_512, 0)
-se = StreamingExtractor(ex, chunk_clips=2048)
-se.run(flat[: 4096 * 48000], offsets[:4097])
-t0 = time.perf_counter(); out = se.run(flat, offsets); dt = time.perf_counter() - t0
-assert int(np.abs(out["status"]).sum()) == 0
-print(f"streaming ingest: {n} clips in {dt*1e3:.1f} ms -> {n/dt:.0f} clips/s ({n*96000/dt/1e9:.1f} GB/s of int16 PCM over PCIe)")
+for threads in (1, 4, 8, 16):
+    se = StreamingExtractor(ex, chunk_clips=2048, copy_threads=threads)
+    se.run(flat[: 4096 * 48000], offsets[:4097])
+    t0 = time.perf_counter(); out = se.run(flat, offsets); dt = time.perf_counter() - t0
+    assert int(np.abs(out["status"]).sum()) == 0
+    print(f"streaming ingest, {threads:2d} copy threads: {n} clips in {dt*1e3:.1f} ms -> {n/dt:.0f} clips/s ({n*96000/dt/1e9:.1f} GB/s of int16 PCM over PCIe)")
