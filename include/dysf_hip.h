@@ -214,6 +214,23 @@ int32_t dysf_resample_batch_dev(DysfResampler* r, const void* d_pcm, int32_t pcm
                                 int32_t n_clips, float* d_out, const int64_t* d_out_offsets, int64_t max_out_len,
                                 void* stream);
 
+/*
+ * Benchmark CNN head of BASELINE.json configs[2] (SURVEY 8d "Config 3"; the reference itself has no CNN):
+ * Conv2d(1->32, 3x3, pad 1) -> ReLU -> MaxPool 2x2 -> Conv2d(32->64, 3x3, pad 1) -> ReLU -> global average pool ->
+ * Linear(64 -> n_classes) on the frame-level rows [n, rows, row_stride] (cols valid columns per row) that
+ * dysf_extract_batch_dev writes.  Weights in PyTorch layout: conv1_w [32,1,3,3], conv2_w [64,32,3,3], fc_w [n_classes,64].
+ * conv1 runs in float32; conv2 on the float16 MFMA with float32 accumulation (the precision configs[4] asks for).
+ *   d_logits [n, n_classes] float32
+ */
+typedef struct DysfCnn DysfCnn;
+const char* dysf_cnn_last_error(void);
+int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w, const float* conv1_b,
+                        const float* conv2_w, const float* conv2_b, const float* fc_w, const float* fc_b,
+                        DysfCnn** out);
+void    dysf_cnn_destroy(DysfCnn* m);
+int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols,
+                             int64_t row_stride, float* d_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ SYMBOLS = (
     "dysf_mlp_last_error", "dysf_mlp_create", "dysf_mlp_destroy", "dysf_mlp_forward_dev",
     "dysf_resampler_last_error", "dysf_resampler_create", "dysf_resampler_destroy", "dysf_resampler_out_len",
     "dysf_resample_batch_dev",
+    "dysf_cnn_last_error", "dysf_cnn_create", "dysf_cnn_destroy", "dysf_cnn_forward_dev",
 )
 
 
@@ -100,6 +101,11 @@ def lib():
     L.dysf_resampler_out_len.argtypes = [vp, i64]
     L.dysf_resampler_out_len.restype = i64
     L.dysf_resample_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i64, vp]
+    L.dysf_cnn_last_error.restype = ctypes.c_char_p
+    L.dysf_cnn_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dysf_cnn_destroy.argtypes = [vp]
+    L.dysf_cnn_destroy.restype = None
+    L.dysf_cnn_forward_dev.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != 1:

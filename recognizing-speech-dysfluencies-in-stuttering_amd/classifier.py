@@ -316,3 +316,56 @@ class CNNHead(nn.Module):
         x = F.max_pool2d(F.relu(self.conv1(x)), 2)
         x = F.relu(self.conv2(x))
         return self.fc(x.mean(dim=(2, 3)))
+
+
+class FusedCNNHead:
+    """``CNNHead`` evaluated by hand-written HIP kernels behind the C ABI (``dysf_cnn_*``): conv1 + ReLU + max-pool in
+    float32, conv2 as an implicit GEMM on the float16 MFMA with float32 accumulation, pooled sums, Linear.  Takes the
+    frame-level tensor [n, rows, T] exactly as ``extract_batch_device(frames=True)`` returns it (no copy, any row
+    pitch).  Built from a ``CNNHead`` (or any module with conv1 / conv2 / fc of those shapes)."""
+
+    def __init__(self, module: "CNNHead", device: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.device = device
+        f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), np.float32)  # noqa: E731
+        arrs = [f(module.conv1.weight), f(module.conv1.bias), f(module.conv2.weight), f(module.conv2.bias),
+                f(module.fc.weight), f(module.fc.bias)]
+        if arrs[0].shape != (32, 1, 3, 3) or arrs[2].shape != (64, 32, 3, 3) or arrs[4].shape[1] != 64:
+            raise ValueError("FusedCNNHead implements Conv(1->32,3x3) / Conv(32->64,3x3) / Linear(64->k) only")
+        self.n_classes = int(arrs[4].shape[0])
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.dysf_cnn_create(device, self.n_classes, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
+                               ctypes.byref(self._h))
+        if rc != 0:
+            raise _lib.DysfError(f"dysf_cnn_create failed ({rc}): {L.dysf_cnn_last_error().decode()}")
+
+    def __call__(self, frames: torch.Tensor, cols=None) -> torch.Tensor:
+        """frames: [n, rows, pitch] float32 CUDA tensor (last dimension contiguous); ``cols`` valid columns per row
+        (default: all)."""
+        import ctypes
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.dim() == 3 and frames.stride(2) == 1
+        assert frames.stride(0) == frames.shape[1] * frames.stride(1)
+        n, rows, pitch = frames.shape[0], frames.shape[1], frames.stride(1)
+        cols = int(frames.shape[2] if cols is None else cols)
+        out = torch.empty((n, self.n_classes), dtype=torch.float32, device=frames.device)
+        L = self._lib.lib()
+        rc = L.dysf_cnn_forward_dev(self._h, ctypes.c_void_p(frames.data_ptr()), n, rows, cols, pitch,
+                                    ctypes.c_void_p(out.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.DysfError(f"dysf_cnn_forward_dev failed ({rc}): {L.dysf_cnn_last_error().decode()}")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lib().dysf_cnn_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

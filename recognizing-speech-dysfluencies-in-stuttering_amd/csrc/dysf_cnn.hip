@@ -1,0 +1,266 @@
+// dysf_cnn.hip -- the benchmark CNN head of BASELINE.json configs[2] / SURVEY.md 8d "Config 3" on the frame-level
+// features:  Conv2d(1->32, 3x3, pad 1) -> ReLU -> MaxPool 2x2 -> Conv2d(32->64, 3x3, pad 1) -> ReLU ->
+// global average pool -> Linear(64 -> n_classes).  (The reference has no CNN; the architecture is SURVEY's.)
+// Three launches on the caller's stream:
+//   conv1 + ReLU + max-pool   float32 FMA, one thread per pooled pixel, all 32 channels; the weights are wave-uniform
+//                             (scalar operands).  Writes the activations channel-last as float16 into a workspace
+//                             with a zero border: act1[clip][62][152][32].
+//   conv2 + ReLU + pooled sum implicit GEMM on v_mfma_f32_16x16x16_f16: M = 16 output channels per wave (its 18 A
+//                             operands -- 9 taps x 2 halves of the 32 input channels -- stay in registers), N = 16
+//                             consecutive pixels of a row, K = 288.  A workgroup stages kRowTile + 2 activation rows
+//                             in LDS (pixel pitch 72 bytes: conflict-light 8-byte B-operand reads), float32
+//                             accumulation, per-channel sums reduced in registers into the workgroup's slot of sums[clip][tile][64].
+//   mean + Linear             one thread per (clip, class).
+// conv2 is 92 % of the arithmetic (332 of 353 MFLOP per clip); float16 operands with float32 accumulation is the
+// precision BASELINE configs[4] asks of the CNN ("fp16 MFMA CNN").
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dysf_hip.h"
+
+namespace {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kC1 = 32, kC2 = 64;
+constexpr int kRowTile = 4;          // conv2 output rows per workgroup
+constexpr int kPixPitch = 36;        // float16 per pixel in LDS (32 channels + 4 of padding = 72 bytes)
+
+struct CnnDev {
+  int H, W, stride;                  // input rows (3*n_mfcc), valid columns (frames), row pitch in floats
+  int PH, PW;                        // pooled size: H/2, W/2
+  int AW;                            // act1 row pitch in pixels (PW + 2, rounded up to a multiple of 16 + 2)
+  int n_classes;
+  const float* w1; const float* b1;  // [32][9], [32]
+  const _Float16* w2p;               // [4 oc tiles][18 steps][64 lanes][4] A operands of conv2
+  const float* b2;                   // [64]
+  const float* wfc; const float* bfc;  // [n_classes][64], [n_classes]
+  _Float16* act1;                    // [clip][PH + 2][AW][32]
+  float* sums;                       // [clip][row tiles][64] per-workgroup partial sums (added in order by the last kernel)
+  int n_tiles;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const float* frames, int n) {
+  const int clip = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= m.PH * m.PW) return;
+  const int py = pix / m.PW, px = pix % m.PW;
+  const float* in = frames + (size_t)clip * m.H * m.stride;
+  float p[4][4];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2, zero outside the [H x W] image
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = 2 * py - 1 + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int x = 2 * px - 1 + c;
+      p[r][c] = (y >= 0 && y < m.H && x >= 0 && x < m.W) ? in[(size_t)y * m.stride + x] : 0.f;
+    }
+  }
+  _Float16* out = m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1;
+#pragma unroll 4
+  for (int c = 0; c < kC1; ++c) {
+    const float* w = m.w1 + c * 9;  // wave-uniform: scalar loads
+    float best = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float s = m.b1[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) s = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], s);
+        best = fmaxf(best, s);
+      }
+    out[c] = (_Float16)fmaxf(best, 0.f);  // max-pool and ReLU commute
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void dysf_cnn_conv2_kernel(CnnDev m, int n) {
+  extern __shared__ __align__(16) _Float16 tile[];  // [kRowTile + 2][AW][kPixPitch]
+  const int clip = blockIdx.y;
+  const int y0 = blockIdx.x * kRowTile;              // first output row of this workgroup
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rows = min(kRowTile, m.PH - y0);
+  // stage rows y0 .. y0 + rows + 1 of the bordered activation map (row r of the map is output row r - 1)
+  {
+    const _Float16* src = m.act1 + ((size_t)clip * (m.PH + 2) + y0) * m.AW * kC1;
+    const int nchunks = (rows + 2) * m.AW * 4;  // 16-byte chunks: 4 per pixel
+    for (int i = tid; i < nchunks; i += 256) {
+      const int pixel = i >> 2, part = i & 3;
+      const int4 v = *(const int4*)(src + (size_t)pixel * kC1 + part * 8);
+      int2* dst = (int2*)(tile + (size_t)pixel * kPixPitch + part * 8);
+      dst[0] = make_int2(v.x, v.y);
+      dst[1] = make_int2(v.z, v.w);
+    }
+  }
+  // this wave's A operands: output channels 16*wave .. +15, 18 K-steps (tap-major, two halves of the input channels)
+  h4 wa[18];
+#pragma unroll
+  for (int s = 0; s < 18; ++s) wa[s] = *(const h4*)(m.w2p + (((size_t)wave * 18 + s) * 64 + lane) * 4);
+  __syncthreads();
+  const int ncol = lane & 15, kg = lane >> 4;
+  float bias[4], rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = m.b2[16 * wave + 4 * kg + r];
+  const int xtiles = (m.PW + 15) / 16;
+  for (int ry = 0; ry < rows; ++ry) {
+    for (int xt = 0; xt < xtiles; ++xt) {
+      const int x = 16 * xt + ncol;               // output pixel column of this lane's B / D column
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx
+        const _Float16* bp = tile + ((size_t)(ry + ky) * m.AW + (x + kx)) * kPixPitch + 4 * kg;
+        const h4 b0 = *(const h4*)bp, b1 = *(const h4*)(bp + 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[2 * t], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[2 * t + 1], b1, acc, 0, 0, 0);
+      }
+      if (x < m.PW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc[r] + bias[r], 0.f);
+      }
+    }
+  }
+  // sum over the 16 pixel columns (lanes with equal lane >> 4); the workgroup's partial sums go to its own slot
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = rs[r];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (ncol == 0) m.sums[((size_t)clip * m.n_tiles + blockIdx.x) * kC2 + 16 * wave + 4 * kg + r] = v;
+  }
+}
+
+__global__ void dysf_cnn_fc_kernel(CnnDev m, int n, float* logits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * m.n_classes) return;
+  const int clip = i / m.n_classes, j = i % m.n_classes;
+  const float inv = 1.0f / (float)(m.PH * m.PW);
+  float s = m.bfc[j];
+  for (int c = 0; c < kC2; ++c) {
+    float tot = 0.f;
+    for (int t = 0; t < m.n_tiles; ++t) tot += m.sums[((size_t)clip * m.n_tiles + t) * kC2 + c];  // fixed order: reproducible
+    s = fmaf(m.wfc[j * kC2 + c], tot * inv, s);
+  }
+  logits[i] = s;
+}
+
+}  // namespace
+
+struct DysfCnn {
+  int device = 0;
+  CnnDev d{};
+  std::vector<void*> bufs;
+  void* act1 = nullptr; size_t act1_clips = 0;
+  void* sums = nullptr; size_t sums_clips = 0;
+  int act_h = 0, act_w = 0;  // geometry the workspace was laid out for
+  bool attr_set = false;
+};
+
+static thread_local std::string g_cerr;
+template <typename T>
+static bool up(DysfCnn* m, const T** dst, const std::vector<T>& src) {
+  void* p = nullptr;
+  if (hipMalloc(&p, src.size() * sizeof(T)) != hipSuccess) return false;
+  m->bufs.push_back(p);
+  if (hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+  *dst = (const T*)p;
+  return true;
+}
+
+extern "C" {
+
+const char* dysf_cnn_last_error(void) { return g_cerr.c_str(); }
+
+int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w, const float* conv1_b,
+                        const float* conv2_w, const float* conv2_b, const float* fc_w, const float* fc_b,
+                        DysfCnn** out) {
+  if (!out || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !fc_w || !fc_b) { g_cerr = "null argument"; return DYSF_E_INVALID; }
+  *out = nullptr;
+  if (n_classes < 1 || n_classes > 64) { g_cerr = "n_classes out of range"; return DYSF_E_INVALID; }
+  DysfCnn* m = new (std::nothrow) DysfCnn();
+  if (!m) { g_cerr = "out of host memory"; return DYSF_E_NOMEM; }
+  m->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete m; g_cerr = "hipSetDevice failed"; return DYSF_E_HIP; }
+  // conv2 A operands: [oc tile][step = tap*2 + half][lane][j]: oc = 16*tile + (lane & 15), ic = 16*half + 4*(lane >> 4) + j
+  std::vector<_Float16> w2p((size_t)4 * 18 * 64 * 4);
+  for (int tile = 0; tile < 4; ++tile)
+    for (int s = 0; s < 18; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 4; ++j) {
+          const int oc = 16 * tile + (l & 15), ic = 16 * (s & 1) + 4 * (l >> 4) + j, tap = s >> 1;
+          w2p[(((size_t)tile * 18 + s) * 64 + l) * 4 + j] = (_Float16)conv2_w[((size_t)oc * kC1 + ic) * 9 + tap];
+        }
+  std::vector<float> w1(conv1_w, conv1_w + kC1 * 9), b1(conv1_b, conv1_b + kC1), b2(conv2_b, conv2_b + kC2),
+      wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
+  m->d.n_classes = n_classes;
+  const bool ok = up(m, &m->d.w1, w1) && up(m, &m->d.b1, b1) && up(m, &m->d.w2p, w2p) && up(m, &m->d.b2, b2) &&
+                  up(m, &m->d.wfc, wfc) && up(m, &m->d.bfc, bfc);
+  if (!ok) { for (void* p : m->bufs) (void)hipFree(p); delete m; g_cerr = "device upload failed"; return DYSF_E_HIP; }
+  *out = m;
+  return 0;
+}
+
+void dysf_cnn_destroy(DysfCnn* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  for (void* p : m->bufs) (void)hipFree(p);
+  if (m->act1) (void)hipFree(m->act1);
+  if (m->sums) (void)hipFree(m->sums);
+  delete m;
+}
+
+int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols, int64_t row_stride,
+                             float* d_logits, void* stream_) {
+  if (!m || !d_frames || !d_logits || n < 0) { g_cerr = "bad argument"; return DYSF_E_INVALID; }
+  if (rows < 2 || cols < 2 || row_stride < cols || rows > 4096 || cols > 65536) { g_cerr = "bad image shape"; return DYSF_E_INVALID; }
+  if (n == 0) return 0;
+  if (n > 65535) { g_cerr = "at most 65535 clips per call"; return DYSF_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipSetDevice(m->device) != hipSuccess) { g_cerr = "hipSetDevice failed"; return DYSF_E_HIP; }
+  CnnDev& d = m->d;
+  d.H = rows; d.W = cols; d.stride = (int)row_stride; d.PH = rows / 2; d.PW = cols / 2;
+  d.AW = (d.PW + 15) / 16 * 16 + 2;  // the last x tile reads up to column 16*xtiles + 1 of the bordered map
+  const size_t act_per_clip = (size_t)(d.PH + 2) * d.AW * kC1 * sizeof(_Float16);
+  if ((size_t)n > m->act1_clips || rows != m->act_h || cols != m->act_w) {
+    if (m->act1) { (void)hipFree(m->act1); m->act1 = nullptr; m->act1_clips = 0; }
+    if (hipMalloc(&m->act1, act_per_clip * n) != hipSuccess) { g_cerr = "hipMalloc of the activation workspace failed"; return DYSF_E_NOMEM; }
+    // the border (and the columns past PW) is zero and is never written afterwards
+    if (hipMemsetAsync(m->act1, 0, act_per_clip * n, stream) != hipSuccess) { g_cerr = "hipMemset failed"; return DYSF_E_HIP; }
+    m->act1_clips = (size_t)n; m->act_h = rows; m->act_w = cols;
+  }
+  d.n_tiles = (d.PH + kRowTile - 1) / kRowTile;
+  if ((size_t)n * d.n_tiles > m->sums_clips) {
+    if (m->sums) { (void)hipFree(m->sums); m->sums = nullptr; }
+    if (hipMalloc(&m->sums, (size_t)n * d.n_tiles * kC2 * sizeof(float)) != hipSuccess) { g_cerr = "hipMalloc failed"; return DYSF_E_NOMEM; }
+    m->sums_clips = (size_t)n * d.n_tiles;
+  }
+  d.act1 = (_Float16*)m->act1; d.sums = (float*)m->sums;
+  const size_t lds = (size_t)(kRowTile + 2) * d.AW * kPixPitch * sizeof(_Float16);
+  if (lds > 160 * 1024) { g_cerr = "feature map too wide for the LDS tile"; return DYSF_E_INVALID; }
+  if (!m->attr_set || true) {
+    if (hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
+    }
+    m->attr_set = true;
+  }
+  hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);
+  hipLaunchKernelGGL(dysf_cnn_conv2_kernel, dim3((d.PH + kRowTile - 1) / kRowTile, n), dim3(256), lds, stream, d, n);
+  hipLaunchKernelGGL(dysf_cnn_fc_kernel, dim3((n * d.n_classes + 255) / 256), dim3(256), 0, stream, d, n, d_logits);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_cerr = hipGetErrorString(e); return DYSF_E_HIP; }
+  return 0;
+}
+
+}  // extern "C"

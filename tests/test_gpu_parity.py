@@ -550,3 +550,32 @@ def test_lane_executor_equals_serial_path(ex512):
         torch.cuda.synchronize()
         assert torch.equal(g["pooled"], want["pooled"]) and torch.equal(g["frames"], want["frames"])
         assert torch.equal(g["logits"], head(want["pooled"]))
+
+
+def test_fused_cnn_head_vs_torch_module(ex512):
+    """BASELINE configs[2]: the CNN head as hand-written HIP kernels (float32 conv1, float16-MFMA conv2 with float32
+    accumulation, dysf_cnn_*) against the same torch module in float32 on the same frame-level features.  There is no
+    reference CNN; the bar is the one configs[4] sets for fp16: finite, arg-max agreement (here 100 % on clips whose
+    float32 margin exceeds the float16 noise) and logits within 2e-3 of the float32 module."""
+    from rsd_amd.classifier import CNNHead, FusedCNNHead
+    clips = np.stack([synth_clip(i) for i in range(24)])
+    pcm = torch.from_numpy(clips.reshape(-1)).cuda()
+    off = torch.arange(0, 25, dtype=torch.int64, device="cuda") * 48000
+    fr = ex512.extract_batch_device(pcm, off, 48000, pooled=False, frames=True)["frames"]
+    cnn = CNNHead().cuda()
+    fused = FusedCNNHead(cnn)
+    with torch.no_grad():
+        want = cnn(fr)
+    got = fused(fr)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err <= 2e-3 * max(1.0, float(want.abs().max())), err
+    margin = want.sort(dim=1).values
+    clear = (margin[:, -1] - margin[:, -2]) > 4 * err
+    assert torch.equal(got.argmax(1)[clear], want.argmax(1)[clear]) and float(clear.float().mean()) >= 0.8
+    # a padded row pitch and a ragged width (odd number of frames, pooled width floor(T/2)) take the same path
+    fr2 = ex512.extract_batch_device(pcm, off, 48000, pooled=False, frames=True, frame_stride=320)["frames"]
+    got2 = fused(fr2, cols=301)
+    assert float((got2 - got).abs().max()) == 0.0
+    fused.close()
