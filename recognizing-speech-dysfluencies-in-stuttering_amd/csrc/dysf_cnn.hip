@@ -5,10 +5,10 @@
 //   conv1 + ReLU + max-pool   float32 FMA, one thread per pooled pixel, all 32 channels; the weights are wave-uniform
 //                             (scalar operands).  Writes the activations channel-last as float16 into a workspace
 //                             with a zero border: act1[clip][62][152][32].
-//   conv2 + ReLU + pooled sum implicit GEMM on v_mfma_f32_16x16x16_f16: M = 16 output channels per wave (its 18 A
-//                             operands -- 9 taps x 2 halves of the 32 input channels -- stay in registers), N = 16
-//                             consecutive pixels of a row, K = 288.  A workgroup stages kRowTile + 2 activation rows
-//                             in LDS (pixel pitch 72 bytes: conflict-light 8-byte B-operand reads), float32
+//   conv2 + ReLU + pooled sum implicit GEMM on v_mfma_f32_16x16x32_f16: M = 16 output channels per wave (its 18 A
+//                             operands -- one v_mfma_f32_16x16x32_f16 step per tap, K = all 32 input channels -- stay
+//                             in registers), N = 16 consecutive pixels of a row, K = 288, two pixel tiles in flight.  A workgroup stages kRowTile + 2 activation rows
+//                             in LDS (pixel pitch 80 bytes: aligned, conflict-light 16-byte B-operand reads), float32
 //                             accumulation, per-channel sums reduced in registers into the workgroup's slot of sums[clip][tile][64].
 //   mean + Linear             one thread per (clip, class).
 // conv2 is 92 % of the arithmetic (332 of 353 MFLOP per clip); float16 operands with float32 accumulation is the
@@ -25,24 +25,28 @@
 
 namespace {
 
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kC1 = 32, kC2 = 64;
 constexpr int kRowTile = 4;          // conv2 output rows per workgroup
-constexpr int kPixPitch = 36;        // float16 per pixel in LDS (32 channels + 4 of padding = 72 bytes)
+constexpr int kPixPitch = 40;        // float16 per pixel in LDS (32 channels + 8 of padding = 80 bytes: 16-byte aligned,
+                                     // neighbouring pixels 20 banks apart)
 
 struct CnnDev {
   int H, W, stride;                  // input rows (3*n_mfcc), valid columns (frames), row pitch in floats
   int PH, PW;                        // pooled size: H/2, W/2
   int AW;                            // act1 row pitch in pixels (PW + 2, rounded up to a multiple of 16 + 2)
   int n_classes;
-  const float* w1; const float* b1;  // [32][9], [32]
-  const _Float16* w2p;               // [4 oc tiles][18 steps][64 lanes][4] A operands of conv2
+  const float* w1;                   // conv1: [32 channels][9 taps + bias]
+  const _Float16* w2p;               // [4 oc tiles][9 taps][64 lanes][8] A operands of conv2
   const float* b2;                   // [64]
   const float* wfc; const float* bfc;  // [n_classes][64], [n_classes]
   _Float16* act1;                    // [clip][PH + 2][AW][32]
-  float* sums;                       // [clip][row tiles][64] per-workgroup partial sums (added in order by the last kernel)
+  float* sums;                       // [clip][row tiles][2][64] per-wave-group partial sums (added in order by the last kernel)
   int n_tiles;
 };
 
@@ -64,71 +68,82 @@ __global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const flo
     }
   }
   _Float16* out = m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1;
+  // the weights are wave-uniform: scalar operands of the FMAs
 #pragma unroll 4
   for (int c = 0; c < kC1; ++c) {
-    const float* w = m.w1 + c * 9;  // wave-uniform: scalar loads
+    const float* w = m.w1 + c * 10;  // [channel][9 taps + bias]
     float best = -INFINITY;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        float s = m.b1[c];
+        float sacc = w[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) s = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], s);
-        best = fmaxf(best, s);
+          for (int kx = 0; kx < 3; ++kx) sacc = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], sacc);
+        best = fmaxf(best, sacc);
       }
     out[c] = (_Float16)fmaxf(best, 0.f);  // max-pool and ReLU commute
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void dysf_cnn_conv2_kernel(CnnDev m, int n) {
+__global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, int n) {
   extern __shared__ __align__(16) _Float16 tile[];  // [kRowTile + 2][AW][kPixPitch]
   const int clip = blockIdx.y;
   const int y0 = blockIdx.x * kRowTile;              // first output row of this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3, half = wave8 >> 2;   // output-channel tile, and which half of the pixel-tile pairs
   const int rows = min(kRowTile, m.PH - y0);
   // stage rows y0 .. y0 + rows + 1 of the bordered activation map (row r of the map is output row r - 1)
   {
     const _Float16* src = m.act1 + ((size_t)clip * (m.PH + 2) + y0) * m.AW * kC1;
     const int nchunks = (rows + 2) * m.AW * 4;  // 16-byte chunks: 4 per pixel
-    for (int i = tid; i < nchunks; i += 256) {
+    for (int i = tid; i < nchunks; i += 512) {
       const int pixel = i >> 2, part = i & 3;
       const int4 v = *(const int4*)(src + (size_t)pixel * kC1 + part * 8);
-      int2* dst = (int2*)(tile + (size_t)pixel * kPixPitch + part * 8);
-      dst[0] = make_int2(v.x, v.y);
-      dst[1] = make_int2(v.z, v.w);
+      *(int4*)(tile + (size_t)pixel * kPixPitch + part * 8) = v;
     }
   }
-  // this wave's A operands: output channels 16*wave .. +15, 18 K-steps (tap-major, two halves of the input channels)
-  h4 wa[18];
+  // this wave's A operands: output channels 16*wave .. +15, one K = 32 step (all input channels) per tap
+  h8 wa[9];
 #pragma unroll
-  for (int s = 0; s < 18; ++s) wa[s] = *(const h4*)(m.w2p + (((size_t)wave * 18 + s) * 64 + lane) * 4);
+  for (int t = 0; t < 9; ++t) wa[t] = *(const h8*)(m.w2p + (((size_t)wave * 9 + t) * 64 + lane) * 8);
   __syncthreads();
   const int ncol = lane & 15, kg = lane >> 4;
   float bias[4], rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = m.b2[16 * wave + 4 * kg + r];
   const int xtiles = (m.PW + 15) / 16;
-  for (int ry = 0; ry < rows; ++ry) {
-    for (int xt = 0; xt < xtiles; ++xt) {
-      const int x = 16 * xt + ncol;               // output pixel column of this lane's B / D column
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int pairs = (xtiles + 1) / 2;
+  for (int item = half; item < rows * pairs; item += 2) {  // the two waves of an output-channel tile alternate
+    const int ry = item / pairs;
+    {
+      const int xt = 2 * (item % pairs);            // two pixel tiles per pass: two independent MFMA chains
+      const int x = 16 * xt + ncol;                 // output pixel column of this lane's B / D column (first tile)
+      const bool two = xt + 1 < xtiles;             // wave-uniform
+      f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t % 3;
-        // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx
-        const _Float16* bp = tile + ((size_t)(ry + ky) * m.AW + (x + kx)) * kPixPitch + 4 * kg;
-        const h4 b0 = *(const h4*)bp, b1 = *(const h4*)(bp + 16);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[2 * t], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[2 * t + 1], b1, acc, 0, 0, 0);
+        // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx; lane kg supplies channels 8kg .. 8kg+7
+        const _Float16* bp = tile + ((size_t)(ry + ky) * m.AW + (x + kx)) * kPixPitch + 8 * kg;
+        const h8 b0 = *(const h8*)bp;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b0, acc0, 0, 0, 0);
+        if (two) {
+          const h8 b1 = *(const h8*)(bp + 16 * kPixPitch);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b1, acc1, 0, 0, 0);
+        }
       }
       if (x < m.PW) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc[r] + bias[r], 0.f);
+        for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc0[r] + bias[r], 0.f);
+      }
+      if (two && x + 16 < m.PW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc1[r] + bias[r], 0.f);
       }
     }
   }
@@ -138,22 +153,25 @@ __global__ __launch_bounds__(256, 2) void dysf_cnn_conv2_kernel(CnnDev m, int n)
     float v = rs[r];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (ncol == 0) m.sums[((size_t)clip * m.n_tiles + blockIdx.x) * kC2 + 16 * wave + 4 * kg + r] = v;
+    if (ncol == 0) m.sums[(((size_t)clip * m.n_tiles + blockIdx.x) * 2 + half) * kC2 + 16 * wave + 4 * kg + r] = v;
   }
 }
 
-__global__ void dysf_cnn_fc_kernel(CnnDev m, int n, float* logits) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * m.n_classes) return;
-  const int clip = i / m.n_classes, j = i % m.n_classes;
-  const float inv = 1.0f / (float)(m.PH * m.PW);
-  float s = m.bfc[j];
-  for (int c = 0; c < kC2; ++c) {
-    float tot = 0.f;
-    for (int t = 0; t < m.n_tiles; ++t) tot += m.sums[((size_t)clip * m.n_tiles + t) * kC2 + c];  // fixed order: reproducible
-    s = fmaf(m.wfc[j * kC2 + c], tot * inv, s);
+// one wave per clip: lane c owns channel c, adds the workgroups' partial sums in tile order (reproducible), then the
+// classes are 64-term dot products reduced across the wave
+__global__ __launch_bounds__(256) void dysf_cnn_fc_kernel(CnnDev m, int n, float* logits) {
+  const int lane = threadIdx.x & 63;
+  const int clip = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (clip >= n) return;
+  float tot = 0.f;
+  for (int t = 0; t < 2 * m.n_tiles; ++t) tot += m.sums[((size_t)clip * 2 * m.n_tiles + t) * kC2 + lane];
+  const float mean = tot * (1.0f / (float)(m.PH * m.PW));
+  for (int j = 0; j < m.n_classes; ++j) {
+    float v = m.wfc[j * kC2 + lane] * mean;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) logits[(size_t)clip * m.n_classes + j] = v + m.bfc[j];
   }
-  logits[i] = s;
 }
 
 }  // namespace
@@ -193,19 +211,24 @@ int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w,
   if (!m) { g_cerr = "out of host memory"; return DYSF_E_NOMEM; }
   m->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete m; g_cerr = "hipSetDevice failed"; return DYSF_E_HIP; }
-  // conv2 A operands: [oc tile][step = tap*2 + half][lane][j]: oc = 16*tile + (lane & 15), ic = 16*half + 4*(lane >> 4) + j
-  std::vector<_Float16> w2p((size_t)4 * 18 * 64 * 4);
+  // conv2 A operands: [oc tile][tap][lane][j]: oc = 16*tile + (lane & 15), ic = 8*(lane >> 4) + j
+  std::vector<_Float16> w2p((size_t)4 * 9 * 64 * 8);
   for (int tile = 0; tile < 4; ++tile)
-    for (int s = 0; s < 18; ++s)
+    for (int tap = 0; tap < 9; ++tap)
       for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 4; ++j) {
-          const int oc = 16 * tile + (l & 15), ic = 16 * (s & 1) + 4 * (l >> 4) + j, tap = s >> 1;
-          w2p[(((size_t)tile * 18 + s) * 64 + l) * 4 + j] = (_Float16)conv2_w[((size_t)oc * kC1 + ic) * 9 + tap];
+        for (int j = 0; j < 8; ++j) {
+          const int oc = 16 * tile + (l & 15), ic = 8 * (l >> 4) + j;
+          w2p[(((size_t)tile * 9 + tap) * 64 + l) * 8 + j] = (_Float16)conv2_w[((size_t)oc * kC1 + ic) * 9 + tap];
         }
-  std::vector<float> w1(conv1_w, conv1_w + kC1 * 9), b1(conv1_b, conv1_b + kC1), b2(conv2_b, conv2_b + kC2),
-      wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
+  // conv1: [channel][tap 0..8, bias]
+  std::vector<float> w1p((size_t)kC1 * 10);
+  for (int c = 0; c < kC1; ++c) {
+    for (int k = 0; k < 9; ++k) w1p[(size_t)c * 10 + k] = conv1_w[c * 9 + k];
+    w1p[(size_t)c * 10 + 9] = conv1_b[c];
+  }
+  std::vector<float> b2(conv2_b, conv2_b + kC2), wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
   m->d.n_classes = n_classes;
-  const bool ok = up(m, &m->d.w1, w1) && up(m, &m->d.b1, b1) && up(m, &m->d.w2p, w2p) && up(m, &m->d.b2, b2) &&
+  const bool ok = up(m, &m->d.w1, w1p) && up(m, &m->d.w2p, w2p) && up(m, &m->d.b2, b2) &&
                   up(m, &m->d.wfc, wfc) && up(m, &m->d.bfc, bfc);
   if (!ok) { for (void* p : m->bufs) (void)hipFree(p); delete m; g_cerr = "device upload failed"; return DYSF_E_HIP; }
   *out = m;
@@ -241,10 +264,10 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
     m->act1_clips = (size_t)n; m->act_h = rows; m->act_w = cols;
   }
   d.n_tiles = (d.PH + kRowTile - 1) / kRowTile;
-  if ((size_t)n * d.n_tiles > m->sums_clips) {
+  if ((size_t)n * d.n_tiles * 2 > m->sums_clips) {
     if (m->sums) { (void)hipFree(m->sums); m->sums = nullptr; }
-    if (hipMalloc(&m->sums, (size_t)n * d.n_tiles * kC2 * sizeof(float)) != hipSuccess) { g_cerr = "hipMalloc failed"; return DYSF_E_NOMEM; }
-    m->sums_clips = (size_t)n * d.n_tiles;
+    if (hipMalloc(&m->sums, (size_t)n * d.n_tiles * 2 * kC2 * sizeof(float)) != hipSuccess) { g_cerr = "hipMalloc failed"; return DYSF_E_NOMEM; }
+    m->sums_clips = (size_t)n * d.n_tiles * 2;
   }
   d.act1 = (_Float16*)m->act1; d.sums = (float*)m->sums;
   const size_t lds = (size_t)(kRowTile + 2) * d.AW * kPixPitch * sizeof(_Float16);
@@ -256,8 +279,8 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
     m->attr_set = true;
   }
   hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);
-  hipLaunchKernelGGL(dysf_cnn_conv2_kernel, dim3((d.PH + kRowTile - 1) / kRowTile, n), dim3(256), lds, stream, d, n);
-  hipLaunchKernelGGL(dysf_cnn_fc_kernel, dim3((n * d.n_classes + 255) / 256), dim3(256), 0, stream, d, n, d_logits);
+  hipLaunchKernelGGL(dysf_cnn_conv2_kernel, dim3((d.PH + kRowTile - 1) / kRowTile, n), dim3(512), lds, stream, d, n);
+  hipLaunchKernelGGL(dysf_cnn_fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d, n, d_logits);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_cerr = hipGetErrorString(e); return DYSF_E_HIP; }
   return 0;
