@@ -317,20 +317,38 @@ __device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool fram
   flush();
 }
 
-// r-th smallest (0-based) of the n positive floats in v, by bitwise binary search; all threads call.
+// r-th smallest (0-based) of the n positive floats in v (bit order = numeric order), by most-significant-byte-first
+// radix selection: four passes over v, each with a 256-bin LDS histogram of the values that still match the prefix.
+// All threads call; hist = 256 ints of LDS scratch, ctl = 2 ints.
 template <int NT>
-__device__ float block_select(const float* v, int n, int r, int* scratch) {
-  unsigned prefix = 0u;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned cand = prefix | (1u << bit);
-    if (threadIdx.x == 0) *scratch = 0;
+__device__ float block_select(const float* v, int n, int r, int* hist, int* ctl) {
+  unsigned prefix = 0u, mask = 0u;
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
     __syncthreads();
-    int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += NT) cnt += (__float_as_uint(v[i]) < cand) ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(scratch, cnt);
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const unsigned u = __float_as_uint(v[i]);
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1);
+    }
     __syncthreads();
-    if (*scratch <= r) prefix = cand;
+    if (threadIdx.x < 64) {  // wave 0: lane l owns bins 4l .. 4l+3; exclusive prefix over the lanes by shuffles
+      const int l = threadIdx.x;
+      const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (l >= o) inc += t; }
+      const int before = inc - tot;
+      if (r >= before && r < inc) {  // exactly one lane: the r-th value falls into one of its four bins
+        int d = 4 * l, c = before;
+        if (r >= c + h0) { c += h0; ++d; if (r >= c + h1) { c += h1; ++d; if (r >= c + h2) { c += h2; ++d; } } }
+        ctl[0] = d; ctl[1] = r - c;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)ctl[0] << (8 * pass);
+    mask |= 0xffu << (8 * pass);
+    r = ctl[1];
     __syncthreads();
   }
   return __uint_as_float(prefix);
@@ -874,10 +892,10 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
   if (npk > 0) {
     float thr;
     if (npk & 1) {
-      thr = block_select<NT>(pk_mag, npk, npk / 2, &imisc[0]);
+      thr = block_select<NT>(pk_mag, npk, npk / 2, (int*)(misc + 128), &imisc[0]);
     } else {
-      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, &imisc[0]);
-      const float hi = block_select<NT>(pk_mag, npk, npk / 2, &imisc[0]);
+      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, (int*)(misc + 128), &imisc[0]);
+      const float hi = block_select<NT>(pk_mag, npk, npk / 2, (int*)(misc + 128), &imisc[0]);
       thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
     }
     if (tid < kTunings) hist[tid] = 0;
