@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--eager-head", action="store_true",
                     help="run the MLP head as the eager torch module instead of the one-kernel HIP head (dysf_mlp_*)")
     ap.add_argument("--no-preheat", action="store_true", help="skip the 60 extra untimed launches ahead of the warm-up steps")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test aid: all ranks run on cuda:0 and the collective goes over gloo (never a measurement)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="HIP streams (and extractor handles) that consecutive batches alternate between; 1 = serial")
     ap.add_argument("--graph", action="store_true",
@@ -105,6 +107,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.share_gpu:   # rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0, gloo carries the gather
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # host-only work first (process pools fork; keep that ahead of any GPU initialisation):
@@ -119,7 +123,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pcm = torch.from_numpy(bank.reshape(-1)).to(dev)
     offsets = (torch.arange(0, BATCH + 1, dtype=torch.int64) * N_SAMPLES).to(dev)
 

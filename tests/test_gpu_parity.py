@@ -579,3 +579,19 @@ def test_fused_cnn_head_vs_torch_module(ex512):
     got2 = fused(fr2, cols=301)
     assert float((got2 - got).abs().max()) == 0.0
     fused.close()
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 path of bench.py (one process per rank, lanes, the logits all-gather on each lane's stream, max-over-ranks
+    timing) rehearsed with two ranks that share this box's GPU and a gloo gather (--share-gpu; never a measurement)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
+           "--share-gpu", "--no-cpu-baseline", "--no-preheat", "--bank-workers", "2"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
