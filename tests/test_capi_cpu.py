@@ -102,3 +102,39 @@ def test_host_emulation_of_wave_fft():
         subprocess.run(["make", "-C", CSRC, "emu_fft_test"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout
+
+
+def test_head_and_resampler_constructors_validate_before_touching_the_gpu():
+    """Argument checks of the classifier-head and resampler entry points return DYSF_E_INVALID (and a message) without any
+    HIP call, so they can be exercised on a box without a GPU."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    h = vp()
+    one = np.ones(8, np.float64)
+    ptr = lambda a: a.ctypes.data_as(vp)  # noqa: E731
+    # MLP: layer count and widths
+    dims = np.array([8, 4, 3], np.int32)
+    ws = (vp * 2)(ptr(np.ones((8, 4))), ptr(np.ones((4, 3))))
+    bs = (vp * 2)(ptr(np.ones(4)), ptr(np.ones(3)))
+    assert L.dysf_mlp_create(0, 0, ptr(dims), ws, bs, ptr(one), ptr(one), ctypes.byref(h)) < 0 and b"layers" in L.dysf_mlp_last_error()
+    bad = np.array([8, 300, 3], np.int32)
+    assert L.dysf_mlp_create(0, 2, ptr(bad), ws, bs, ptr(one), ptr(one), ctypes.byref(h)) < 0 and b"width" in L.dysf_mlp_last_error()
+    assert L.dysf_mlp_create(0, 2, ptr(dims), None, bs, ptr(one), ptr(one), ctypes.byref(h)) < 0
+    # SVC: shapes must add up
+    ns = np.array([2, 1, 1], np.int32)
+    assert L.dysf_svc_create(0, 8, 3, 5, ptr(np.ones((5, 8))), ptr(np.ones((2, 5))), ptr(np.ones(3)), ptr(ns), None, None,
+                             ctypes.c_double(0.1), ptr(one), ptr(one), ctypes.byref(h)) < 0
+    assert b"n_support" in L.dysf_svc_last_error()
+    assert L.dysf_svc_create(0, 8, 3, 4, ptr(np.ones((4, 8))), ptr(np.ones((2, 4))), ptr(np.ones(3)), ptr(ns), None, None,
+                             ctypes.c_double(-1.0), ptr(one), ptr(one), ctypes.byref(h)) < 0
+    # forest: children must follow their parent
+    feat = np.array([0, -2, -2], np.int32); thr = np.zeros(3); left = np.array([1, -1, -1], np.int32)
+    right = np.array([0, -1, -1], np.int32)   # right child 0 <= parent 0: a walk could loop
+    val = np.ones((3, 2)); root = np.array([0], np.int32)
+    assert L.dysf_forest_create(0, 8, 2, 1, 3, ptr(feat), ptr(thr), ptr(left), ptr(right), ptr(val), ptr(root), ptr(one), ptr(one),
+                                ctypes.byref(h)) < 0 and b"children" in L.dysf_forest_last_error()
+    # CNN and resampler
+    f32 = np.ones(64 * 32 * 9, np.float32)
+    assert L.dysf_cnn_create(0, 0, ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ctypes.byref(h)) < 0
+    assert L.dysf_resampler_create(0, 0, 441, ptr(one), 8, 0, ctypes.byref(h)) < 0 and b"shape" in L.dysf_resampler_last_error()
+    assert not h.value

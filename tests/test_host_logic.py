@@ -174,3 +174,29 @@ def test_resampler_filter_design_equals_scipy():
         assert np.abs(taps[n_pre_pad:] - h).max() <= 1e-13 * up
         assert n_pre_remove == (half_len + n_pre_pad) // down
     assert R.output_length(66150, 320, 441) == 48000 and R.output_length(1, 320, 441) == 1 and R.output_length(0, 320, 441) == 0
+
+
+def test_sharding_properties_hypothesis():
+    """shard_range / shard_by_samples partition the clip index space: contiguous, disjoint, complete, balanced."""
+    from hypothesis import given, settings, strategies as st
+    from rsd_amd.pipeline import shard_by_samples, shard_range
+
+    @settings(max_examples=200, deadline=None)
+    @given(n=st.integers(0, 5000), world=st.integers(1, 16))
+    def check_range(n, world):
+        spans = [shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert all(s >= 0 for s in sizes) and max(sizes) <= -(-n // world)
+
+    @settings(max_examples=100, deadline=None)
+    @given(lens=st.lists(st.integers(1, 100000), min_size=1, max_size=200), world=st.integers(1, 8))
+    def check_samples(lens, world):
+        b = shard_by_samples(np.array(lens), world)
+        assert b[0] == 0 and b[-1] == len(lens) and (np.diff(b) >= 0).all()
+        per = [int(np.sum(lens[b[i]:b[i + 1]])) for i in range(world)]
+        assert sum(per) == sum(lens) and max(per) <= sum(lens) / world + max(lens)
+
+    check_range()
+    check_samples()
