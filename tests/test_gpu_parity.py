@@ -578,6 +578,13 @@ def test_fused_cnn_head_vs_torch_module(ex512):
     fr2 = ex512.extract_batch_device(pcm, off, 48000, pooled=False, frames=True, frame_stride=320)["frames"]
     got2 = fused(fr2, cols=301)
     assert float((got2 - got).abs().max()) == 0.0
+    # small and odd shapes (a single pixel tile, odd rows / columns dropped by the pooling floor)
+    for shape in ((3, 10, 13), (2, 7, 40), (5, 32, 33)):
+        x = torch.randn(*shape, device="cuda")
+        with torch.no_grad():
+            w = cnn(x)
+        g = fused(x)
+        assert float((g - w).abs().max()) <= 2e-3 * max(1.0, float(w.abs().max())), shape
     fused.close()
 
 
