@@ -92,24 +92,34 @@ class FeatureExtractor:
 
     # ---------------------------------------------------------------- device buffers (torch is plumbing only)
     def extract_batch_device(self, pcm, offsets, max_samples: int, pooled: bool = True, frames: bool = False,
-                             frame_stride: Optional[int] = None, tuning: bool = False):
+                             frame_stride: Optional[int] = None, tuning: bool = False, out: Optional[dict] = None):
         """Hot path: ``pcm`` (int16 or float32) and ``offsets`` (int64, [n+1]) are CUDA/HIP torch tensors that
-        stay resident; outputs are torch tensors on the same device.  Only enqueues work on the current stream."""
+        stay resident; outputs are torch tensors on the same device.  Only enqueues work on the current stream.
+        ``out``: optional dict of preallocated, contiguous output tensors (``status`` and whichever of ``pooled`` /
+        ``frames`` / ``tuning`` are wanted) to write into instead of allocating -- e.g. row slices of larger tensors."""
         import torch
         assert pcm.is_cuda and offsets.is_cuda and offsets.dtype == torch.int64 and pcm.is_contiguous()
+        assert offsets.is_contiguous()
         kind = {torch.int16: _lib.PCM_I16, torch.float32: _lib.PCM_F32}[pcm.dtype]
         n = offsets.numel() - 1
         dev = pcm.device
         t_max = self.params.n_frames(max_samples)
         fs = int(frame_stride or t_max)
-        res = {}
-        res["status"] = torch.empty(n, dtype=torch.int32, device=dev)
-        if pooled:
-            res["pooled"] = torch.empty((n, self.pooled_dim), dtype=torch.float32, device=dev)
-        if frames:
-            res["frames"] = torch.empty((n, self.frame_rows, fs), dtype=torch.float32, device=dev)
-        if tuning:
-            res["tuning"] = torch.empty(n, dtype=torch.int32, device=dev)
+        if out is not None:
+            res = out
+            for k, shape, dt in (("status", (n,), torch.int32), ("pooled", (n, self.pooled_dim), torch.float32),
+                                 ("frames", (n, self.frame_rows, fs), torch.float32), ("tuning", (n,), torch.int32)):
+                if k in res:
+                    assert res[k].is_contiguous() and tuple(res[k].shape) == shape and res[k].dtype == dt, k
+        else:
+            res = {}
+            res["status"] = torch.empty(n, dtype=torch.int32, device=dev)
+            if pooled:
+                res["pooled"] = torch.empty((n, self.pooled_dim), dtype=torch.float32, device=dev)
+            if frames:
+                res["frames"] = torch.empty((n, self.frame_rows, fs), dtype=torch.float32, device=dev)
+            if tuning:
+                res["tuning"] = torch.empty(n, dtype=torch.int32, device=dev)
         ptr = lambda k: ctypes.c_void_p(res[k].data_ptr()) if k in res else None  # noqa: E731
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(_lib.lib().dysf_extract_batch_dev(

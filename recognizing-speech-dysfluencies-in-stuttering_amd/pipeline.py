@@ -120,3 +120,34 @@ class LaneExecutor:
             if after is not None:
                 after(res)
         return res
+
+    @torch.no_grad()
+    def extract_large(self, pcm: torch.Tensor, offsets: torch.Tensor, max_samples: int, chunk_clips: int = 2048,
+                      pooled: bool = True, frames: bool = False, frame_stride=None, tuning: bool = False):
+        """One big resident batch (BASELINE configs[3]: tens of thousands of clips per GPU) cut into chunks of
+        ``chunk_clips`` that alternate between the lanes and write into row slices of ONE set of output tensors, so that
+        chunk i+1's STFT kernel overlaps chunk i's MFCC kernel.  Same numbers as a single call; forks from and joins
+        into the current stream, so the result is ready for it on return (asynchronously)."""
+        n = offsets.numel() - 1
+        ex0 = self.extractors[0]
+        dev = pcm.device
+        fs = int(frame_stride or ex0.params.n_frames(max_samples))
+        out = {"status": torch.empty(n, dtype=torch.int32, device=dev)}
+        if pooled:
+            out["pooled"] = torch.empty((n, ex0.pooled_dim), dtype=torch.float32, device=dev)
+        if frames:
+            out["frames"] = torch.empty((n, ex0.frame_rows, fs), dtype=torch.float32, device=dev)
+        if tuning:
+            out["tuning"] = torch.empty(n, dtype=torch.int32, device=dev)
+        self.fork()
+        for a in range(0, n, chunk_clips):
+            b = min(n, a + chunk_clips)
+            k = self._i % len(self.streams)
+            self._i += 1
+            with torch.cuda.stream(self.streams[k]):
+                for t in out.values():
+                    t.record_stream(self.streams[k])
+                self.extractors[k].extract_batch_device(pcm, offsets[a:b + 1], max_samples, frame_stride=fs,
+                                                        out={key: t[a:b] for key, t in out.items()})
+        self.join()
+        return out

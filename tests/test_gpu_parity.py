@@ -602,3 +602,22 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_lane_executor_large_batch_equals_single_call(ex512):
+    """LaneExecutor.extract_large: one resident batch of 5000 ragged clips cut into 1024-clip chunks over three lanes,
+    written into slices of one output set -- bit-identical to the single-launch result."""
+    from rsd_amd.pipeline import LaneExecutor
+    rng = np.random.default_rng(3)
+    base = [synth_clip(i, n=4000 + 531 * i) for i in range(16)]
+    idx = rng.integers(0, 16, size=5000)
+    lens = np.array([len(base[i]) for i in idx])
+    pcm = torch.from_numpy(np.concatenate([base[i] for i in idx])).cuda()
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+    ms = int(lens.max())
+    want = ex512.extract_batch_device(pcm, off, ms, pooled=True, frames=True)
+    lanes = LaneExecutor(B512, 0, 3)
+    got = lanes.extract_large(pcm, off, ms, chunk_clips=1024, pooled=True, frames=True)
+    torch.cuda.synchronize()
+    for k in ("status", "pooled", "frames"):
+        assert torch.equal(got[k], want[k]), k
