@@ -209,6 +209,18 @@ def main():
         ev1.record()
         fence()
         dt = time.perf_counter() - t0
+        # for transparency: the same step strictly serially on one stream (outside the timed region, not `value`)
+        serial_ms = None
+        if graph is None and n_lanes > 1:
+            sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_serial = min(50, args.steps)
+            sv0.record()
+            for _ in range(n_serial):
+                r1 = ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
+                gather_rows(head(r1["pooled"]), BATCH * world, rank, world)
+            sv1.record()
+            torch.cuda.synchronize(dev)
+            serial_ms = sv0.elapsed_time(sv1) / n_serial
         # per-kernel durations: a few extra launches outside the timed region, events inside the library
         ex.kernel_timing(True)
         for _ in range(min(10, args.steps)):
@@ -248,7 +260,7 @@ def main():
                                    "frame-level [1024,120,301] fp32 + pooled [1024,240] fp32, then MLP head -> logits "
                                    "[1024,3] and (N>1) RCCL all-gather of the logits",
                        "clips_per_gpu": BATCH, "samples_per_clip": N_SAMPLES, "n_fft": 512, "hop": 160,
-                       "n_mels": 64, "n_mfcc": 40, "frames_per_clip": T, "untimed_preheat_launches": 0 if args.no_preheat else 60, "parallelism": f"clip-sharded x{world}", "launch": "hipGraph replay" if graph is not None else ("eager, batches alternate between %d streams" % n_lanes if n_lanes > 1 else "eager, one stream")},
+                       "n_mels": 64, "n_mfcc": 40, "frames_per_clip": T, "untimed_preheat_launches": 0 if args.no_preheat else 60, "one_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4), "parallelism": f"clip-sharded x{world}", "launch": "hipGraph replay" if graph is not None else ("eager, batches alternate between %d streams" % n_lanes if n_lanes > 1 else "eager, one stream")},
             # dominant kernel = the STFT+mel kernel; its own algorithmic bytes are the PCM it reads plus the log-mel it
             # writes.  `path` prices the whole feature launch (both kernels) with the SURVEY 8d bytes (no intermediates).
             "roofline": {"bound": "hbm", "kernel": "dysf_stft_mel_kernel<256, i16, 256>",
