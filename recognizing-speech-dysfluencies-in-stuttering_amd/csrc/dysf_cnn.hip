@@ -1,7 +1,8 @@
 // dysf_cnn.hip -- the benchmark CNN head of BASELINE.json configs[2] / SURVEY.md 8d "Config 3" on the frame-level
 // features:  Conv2d(1->32, 3x3, pad 1) -> ReLU -> MaxPool 2x2 -> Conv2d(32->64, 3x3, pad 1) -> ReLU ->
 // global average pool -> Linear(64 -> n_classes).  (The reference has no CNN; the architecture is SURVEY's.)
-// Three launches on the caller's stream:
+// Two launches on the caller's stream (three with DYSF_CNN_SPLIT=1, which keeps conv1 as its own kernel and the
+// activations in an HBM workspace; the default computes conv1 straight into conv2's LDS tile):
 //   conv1 + ReLU + max-pool   float32 FMA, one thread per pooled pixel, all 32 channels; the weights are wave-uniform
 //                             (scalar operands).  Writes the activations channel-last as float16 into a workspace
 //                             with a zero border: act1[clip][62][152][32].
@@ -17,6 +18,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -51,12 +53,8 @@ struct CnnDev {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const float* frames, int n) {
-  const int clip = blockIdx.y;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= m.PH * m.PW) return;
-  const int py = pix / m.PW, px = pix % m.PW;
-  const float* in = frames + (size_t)clip * m.H * m.stride;
+// conv1 + ReLU + 2x2 max-pool of one pooled pixel (py, px), all 32 channels, written as float16 to dst[0..31]
+__device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int py, int px, _Float16* dst) {
   float p[4][4];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2, zero outside the [H x W] image
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -67,7 +65,6 @@ __global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const flo
       p[r][c] = (y >= 0 && y < m.H && x >= 0 && x < m.W) ? in[(size_t)y * m.stride + x] : 0.f;
     }
   }
-  _Float16* out = m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1;
   // the weights are wave-uniform: scalar operands of the FMAs
 #pragma unroll 4
   for (int c = 0; c < kC1; ++c) {
@@ -84,12 +81,22 @@ __global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const flo
           for (int kx = 0; kx < 3; ++kx) sacc = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], sacc);
         best = fmaxf(best, sacc);
       }
-    out[c] = (_Float16)fmaxf(best, 0.f);  // max-pool and ReLU commute
+    dst[c] = (_Float16)fmaxf(best, 0.f);  // max-pool and ReLU commute
   }
 }
 
+__global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const float* frames, int n) {
+  const int clip = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= m.PH * m.PW) return;
+  const int py = pix / m.PW, px = pix % m.PW;
+  conv1_pool_pixel(m, frames + (size_t)clip * m.H * m.stride, py, px,
+                   m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, int n) {
+template <bool FUSED>
+__global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const float* frames, int n) {
   extern __shared__ __align__(16) _Float16 tile[];  // [kRowTile + 2][AW][kPixPitch]
   const int clip = blockIdx.y;
   const int y0 = blockIdx.x * kRowTile;              // first output row of this workgroup
@@ -97,8 +104,25 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, int n)
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3, half = wave8 >> 2;   // output-channel tile, and which half of the pixel-tile pairs
   const int rows = min(kRowTile, m.PH - y0);
-  // stage rows y0 .. y0 + rows + 1 of the bordered activation map (row r of the map is output row r - 1)
-  {
+  // rows y0 .. y0 + rows + 1 of the bordered activation map (row r of the map is pooled row r - 1, column c pooled
+  // column c - 1; the border and the columns past PW are zero)
+  if (FUSED) {
+    // conv1 + pool computed straight into the tile: no activation round trip through HBM (the halo rows are computed
+    // by both neighbours: 1.5x the conv1 arithmetic, which overlaps other workgroups' MFMA phase)
+    const float* in = frames + (size_t)clip * m.H * m.stride;
+    const int npix = (rows + 2) * m.AW;
+    for (int i = tid; i < npix; i += 512) {
+      const int j = i / m.AW, c = i % m.AW;
+      const int py = y0 + j - 1, px = c - 1;
+      _Float16* dst = tile + (size_t)i * kPixPitch;
+      if (py >= 0 && py < m.PH && px >= 0 && px < m.PW) {
+        conv1_pool_pixel(m, in, py, px, dst);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(int4*)(dst + 8 * q) = make_int4(0, 0, 0, 0);
+      }
+    }
+  } else {
     const _Float16* src = m.act1 + ((size_t)clip * (m.PH + 2) + y0) * m.AW * kC1;
     const int nchunks = (rows + 2) * m.AW * 4;  // 16-byte chunks: 4 per pixel
     for (int i = tid; i < nchunks; i += 512) {
@@ -184,6 +208,7 @@ struct DysfCnn {
   void* sums = nullptr; size_t sums_clips = 0;
   int act_h = 0, act_w = 0;  // geometry the workspace was laid out for
   bool attr_set = false;
+  bool fused = true;  // DYSF_CNN_SPLIT=1: conv1 as its own kernel with the activations in HBM
 };
 
 static thread_local std::string g_cerr;
@@ -228,6 +253,7 @@ int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w,
   }
   std::vector<float> b2(conv2_b, conv2_b + kC2), wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
   m->d.n_classes = n_classes;
+  if (const char* e = std::getenv("DYSF_CNN_SPLIT")) m->fused = std::atoi(e) == 0;
   const bool ok = up(m, &m->d.w1, w1p) && up(m, &m->d.w2p, w2p) && up(m, &m->d.b2, b2) &&
                   up(m, &m->d.wfc, wfc) && up(m, &m->d.bfc, bfc);
   if (!ok) { for (void* p : m->bufs) (void)hipFree(p); delete m; g_cerr = "device upload failed"; return DYSF_E_HIP; }
@@ -256,7 +282,7 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   d.H = rows; d.W = cols; d.stride = (int)row_stride; d.PH = rows / 2; d.PW = cols / 2;
   d.AW = (d.PW + 15) / 16 * 16 + 2;  // the last x tile reads up to column 16*xtiles + 1 of the bordered map
   const size_t act_per_clip = (size_t)(d.PH + 2) * d.AW * kC1 * sizeof(_Float16);
-  if ((size_t)n > m->act1_clips || rows != m->act_h || cols != m->act_w) {
+  if (!m->fused && ((size_t)n > m->act1_clips || rows != m->act_h || cols != m->act_w)) {
     if (m->act1) { (void)hipFree(m->act1); m->act1 = nullptr; m->act1_clips = 0; }
     if (hipMalloc(&m->act1, act_per_clip * n) != hipSuccess) { g_cerr = "hipMalloc of the activation workspace failed"; return DYSF_E_NOMEM; }
     // the border (and the columns past PW) is zero and is never written afterwards
@@ -273,13 +299,19 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   const size_t lds = (size_t)(kRowTile + 2) * d.AW * kPixPitch * sizeof(_Float16);
   if (lds > 160 * 1024) { g_cerr = "feature map too wide for the LDS tile"; return DYSF_E_INVALID; }
   if (!m->attr_set || true) {
-    if (hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
     }
     m->attr_set = true;
   }
-  hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);
-  hipLaunchKernelGGL(dysf_cnn_conv2_kernel, dim3((d.PH + kRowTile - 1) / kRowTile, n), dim3(512), lds, stream, d, n);
+  const dim3 grid2((d.PH + kRowTile - 1) / kRowTile, n);
+  if (m->fused) {
+    hipLaunchKernelGGL(dysf_cnn_conv2_kernel<true>, grid2, dim3(512), lds, stream, d, d_frames, n);
+  } else {
+    hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);
+    hipLaunchKernelGGL(dysf_cnn_conv2_kernel<false>, grid2, dim3(512), lds, stream, d, d_frames, n);
+  }
   hipLaunchKernelGGL(dysf_cnn_fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d, n, d_logits);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_cerr = hipGetErrorString(e); return DYSF_E_HIP; }
