@@ -37,6 +37,11 @@ from oracle import dysf_oracle as O  # noqa: E402
 REF = os.environ.get("DYSF_REFERENCE", "/root/reference")
 N_PAIRS = 12
 CONFIG1_CLIP = "F_0050_10y9m_1 (mp3cut.net)10.wav"
+# Clips on which a GPU build has missed the reference before (tests/golden/validate_888_gpu.json of round 1): the two whose
+# tuning histogram arg-max flipped under float32 FFT noise, and two whose mfcc_mean_0 sits one float32 ulp from the 1e-4
+# limit (the clip maximum of the log-mel decides the top_db floor of every clamped cell).
+EDGE_CLIPS = ("M_0091_11y4m_1 (mp3cut.net) (2).wav", "M_1107_38y0m_1 (mp3cut.net)2.wav",
+              "M_0098_07y8m_1 (mp3cut.net) (4).wav", "M_1105_21y0m_1  (mp3cut.net)35.wav")
 AUDIO_EXTS = (".wav", ".mp3", ".flac", ".m4a", ".ogg")  # pipeline1.py:77
 
 
@@ -88,6 +93,8 @@ def copy_pairs(lengths):
     chosen = sorted(lengths, key=lambda w: (lengths[w], w))[:N_PAIRS]
     # plus the 3 s-class clip SURVEY.md section 8d names for BASELINE configs[0]
     chosen += [w for w in lengths if os.path.basename(w) == CONFIG1_CLIP]
+    for name in EDGE_CLIPS:
+        chosen += [w for w in lengths if os.path.basename(w) == name]
     index = []
     for i, w in enumerate(chosen):
         stem = os.path.basename(w)[:-4]
@@ -97,6 +104,22 @@ def copy_pairs(lengths):
         index.append({"id": f"{i:02d}", "reference_stem": stem, "n_samples": lengths[w]})
     with open(os.path.join(out, "index.json"), "w") as f:
         json.dump(index, f, indent=1)
+
+
+def export_all(lengths):
+    """All 888 pairs into tests/golden/_all888/ (git-ignored, never committed): input of tools/validate_888_gpu.py, which
+    runs on the GPU box where /root/reference does not exist."""
+    out = os.path.join(HERE, "_all888")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    index = []
+    for i, w in enumerate(sorted(lengths)):
+        stem = os.path.basename(w)[:-4]
+        shutil.copyfile(w, os.path.join(out, f"{i:03d}.wav"))
+        shutil.copyfile(os.path.join(REF, "cache_features", stem + "_clean_feats.npy"), os.path.join(out, f"{i:03d}.npy"))
+        index.append({"id": f"{i:03d}", "stem": stem, "n_samples": lengths[w]})
+    with open(os.path.join(out, "index.json"), "w") as f:
+        json.dump(index, f)
 
 
 def list_audio_files(root):  # same walk order as pipeline1.py:91-97
@@ -247,6 +270,10 @@ if __name__ == "__main__":
         sys.exit(0)
     lengths = validate_all()
     copy_pairs(lengths)
+    if "--all888" in sys.argv:
+        export_all(lengths)
+    if "--pairs-only" in sys.argv:
+        sys.exit(0)
     classifier_fixture()
     forest_fixture()
     svc_fixture()

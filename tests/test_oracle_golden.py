@@ -20,7 +20,7 @@ def _pairs(golden_dir):
 def test_validation_record_of_all_888_reference_pairs(golden_dir):
     rec = json.load(open(os.path.join(golden_dir, "validate_888.json")))
     assert rec["n_pairs"] == 888 and rec["n_over_1e-4"] == 0
-    assert rec["max_abs_diff"] <= 1e-4
+    assert rec["max_abs_diff"] <= 6.2e-5   # one float32 ulp of a value in [512, 1024): mfcc_mean_0 of three clips
     assert rec["block_max_abs_diff"]["chroma_stats"] <= 1e-6 and rec["block_max_abs_diff"]["text"] == 0.0
 
 
@@ -31,11 +31,29 @@ def test_oracle_reproduces_committed_reference_vectors(golden_dir):
         assert gold.dtype == np.float32 and gold.shape == (149,)
         feats = O.extract_features(O.pcm16_to_float(pcm), sr)
         assert feats.dtype == np.float32
-        assert np.abs(feats - gold).max() <= 1e-4, e
+        assert np.abs(feats - gold).max() <= 6.2e-5, e
         assert np.abs(feats[120:144] - gold[120:144]).max() <= 1e-6  # chroma incl. the tuning decision
         assert (feats[144:] == 0).all() and (gold[144:] == 0).all()
         n += 1
-    assert n == 13
+    assert n == 17   # 12 shortest + the config-1 clip + the four clips earlier GPU builds missed (make_golden.EDGE_CLIPS)
+
+
+def test_cabs32_is_numpy_abs_on_an_fma_host():
+    """cabs32 spells out NumPy's SIMD complex64 abs (FMA form); on a host with FMA3 / AVX512 the two agree bit for bit."""
+    from numpy._core._multiarray_umath import __cpu_features__ as feats
+    if not (feats.get("FMA3") or feats.get("AVX512F") or feats.get("ASIMD")):
+        pytest.skip("host NumPy uses the unfused form")
+    rng = np.random.default_rng(1)
+    z = ((rng.standard_normal(200000) + 1j * rng.standard_normal(200000)) * np.exp(rng.uniform(-20, 20, 200000))).astype(np.complex64)
+    z[:4] = [0, 1e-30, 3e38 + 3e38j, 1 + 0j]
+    assert (np.abs(z) == O.cabs32(z)).all()
+
+
+def test_log10_f32_is_correctly_rounded():
+    x = np.exp(np.random.default_rng(2).uniform(-23, 12, 100000)).astype(np.float32)
+    got = O.log10_f32(x)
+    exact = np.log10(x.astype(np.float64))
+    assert got.dtype == np.float32 and (np.abs(got.astype(np.float64) - exact) <= 0.5000001 * np.spacing(np.abs(got))).all()
 
 
 def test_config1_clip_is_among_the_fixtures(golden_dir):
