@@ -38,6 +38,7 @@ extern "C" {
 #define DYSF_TOO_SHORT     1 /* fewer than delta_width frames: librosa.feature.delta raises (p1:217)   */
 #define DYSF_NONFINITE     2 /* NaN/Inf sample: librosa.util.valid_audio raises                         */
 #define DYSF_EMPTY         3 /* zero-length clip                                                        */
+#define DYSF_TOO_LONG      4 /* device entry point only: the clip has more samples than the caller's max_samples */
 
 /* function return codes */
 #define DYSF_E_INVALID    (-1) /* bad argument / unsupported parameter combination */
@@ -63,7 +64,12 @@ typedef struct DysfParams {
   int32_t rich;        /* 1: append main.py:738-754's descriptors to the pooled row: spectral-contrast mean (7) */
                        /*    and std (7), mean zero-crossing rate, mean RMS, mean spectral centroid (17 floats); */
                        /*    2048 must be a whole number of hops (frame_length of librosa's zcr / rms)            */
-  int32_t reserved[4];
+  int32_t parity;      /* 1: reproduce the reference's float rounding steps where they decide results: float64 FFT */
+                       /*    rounded to complex64 and NumPy's complex abs (librosa.stft keeps a float64 product of  */
+                       /*    frame and window), NumPy's pairwise float32 mean / std (pipeline1.py:220-221).  The     */
+                       /*    tuning histogram of chroma_stft (p1:227) is a near-tie in most clips and follows the    */
+                       /*    reference only with this set; 0 = float32 FFT, float64 statistics (faster)             */
+  int32_t reserved[3];
 } DysfParams;
 
 #define DYSF_PRESET_REFERENCE_149 0 /* pipeline1.py / main1.py: 2048/512/128 mel/20 mfcc + chroma      */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DYSF_LIB") or os.path.join(_HERE, "libdysf_hip.so")  # DYSF_LIB: diagnostic builds
 
 DYSF_OK, DYSF_TOO_SHORT, DYSF_NONFINITE, DYSF_EMPTY = 0, 1, 2, 3
-STATUS_NAMES = {0: "OK", 1: "TOO_SHORT", 2: "NONFINITE", 3: "EMPTY"}
+STATUS_NAMES = {0: "OK", 1: "TOO_SHORT", 2: "NONFINITE", 3: "EMPTY", 4: "TOO_LONG"}
 PCM_I16, PCM_F32 = 0, 1
 PRESET_REFERENCE_149, PRESET_BENCH_512 = 0, 1
 
@@ -32,7 +32,7 @@ class DysfParams(ctypes.Structure):
         ("n_mels", ctypes.c_int32), ("n_mfcc", ctypes.c_int32),
         ("fmin", ctypes.c_float), ("fmax", ctypes.c_float), ("top_db", ctypes.c_float), ("amin", ctypes.c_float),
         ("delta_width", ctypes.c_int32), ("chroma", ctypes.c_int32), ("rich", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("parity", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
     ]
 
 

@@ -50,13 +50,14 @@ struct DysfHandle {
   float* d_window_i16 = nullptr;
   float *d_window = nullptr, *d_stage_tw = nullptr, *d_post_tw = nullptr,
         *d_chroma_pack = nullptr;
+  double *d_window64 = nullptr, *d_window64_i16 = nullptr, *d_stage_tw64 = nullptr, *d_post_tw64 = nullptr;  // parity presets
   double* d_dct_pack = nullptr;
   float* d_dct_pack32 = nullptr;
   double* d_dct_rowsum = nullptr;
   int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   // workspace / staging
-  DevBuf ws_rich;
+  DevBuf ws_rich, ws_S, ws_stat;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
@@ -89,11 +90,11 @@ int32_t dysf_params_preset(int32_t preset, DysfParams* p) {
   std::memset(p, 0, sizeof(*p));
   p->sr = 16000; p->fmin = 0.f; p->fmax = 0.f; p->top_db = 80.f; p->amin = 1e-10f; p->delta_width = 9;
   if (preset == DYSF_PRESET_REFERENCE_149) {
-    p->n_fft = 2048; p->hop = 512; p->n_mels = 128; p->n_mfcc = 20; p->chroma = 1;
+    p->n_fft = 2048; p->hop = 512; p->n_mels = 128; p->n_mfcc = 20; p->chroma = 1; p->parity = 1;
   } else if (preset == DYSF_PRESET_BENCH_512) {
     p->n_fft = 512; p->hop = 160; p->n_mels = 64; p->n_mfcc = 40; p->chroma = 0;
   } else if (preset == DYSF_PRESET_MAIN_286) {
-    p->n_fft = 512; p->hop = 256; p->n_mels = 128; p->n_mfcc = 40; p->chroma = 1; p->rich = 1;
+    p->n_fft = 512; p->hop = 256; p->n_mels = 128; p->n_mfcc = 40; p->chroma = 1; p->rich = 1; p->parity = 1;
   } else {
     return fail(DYSF_E_INVALID, "unknown preset");
   }
@@ -124,6 +125,14 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
       for (float& w : w16) w *= 1.0f / 32768.0f;  // exact
       rc |= upload(&h->d_window_i16, w16);
     }
+    if (p->parity) {
+      rc |= upload(&h->d_window64, h->t.window64_half);
+      std::vector<double> w16(h->t.window64_half);
+      for (double& w : w16) w *= 1.0 / 32768.0;  // exact
+      rc |= upload(&h->d_window64_i16, w16);
+      rc |= upload(&h->d_stage_tw64, h->t.stage_tw64);
+      rc |= upload(&h->d_post_tw64, h->t.post_tw64);
+    }
     rc |= upload(&h->d_stage_tw, h->t.stage_tw);
     rc |= upload(&h->d_post_tw, h->t.post_tw);
     rc |= upload(&h->d_dct_pack, h->t.dct_pack64);
@@ -144,6 +153,8 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
     (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
+    (void)hipFree(h->d_window64); (void)hipFree(h->d_window64_i16); (void)hipFree(h->d_stage_tw64); (void)hipFree(h->d_post_tw64);
+    h->ws_S.release(); h->ws_stat.release();
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
@@ -280,17 +291,21 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.pcm = d_pcm; a.hop = p.hop; a.sr = p.sr; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
   a.pooled_dim = dysf_pooled_dim(h); a.frame_stride = frame_stride;
   a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel; a.dbg_stamps = h->dbg_stamps;
-  a.top_db = p.top_db; a.amin = p.amin; a.db_amin = (float)(10.0 * std::log10((double)p.amin)); a.chroma = p.chroma ? 1 : 0;
+  // power_to_db of a floor cell: float32(10) * float32(log10(amin)), the reference's two roundings (-100 for 1e-10)
+  a.top_db = p.top_db; a.amin = p.amin; a.db_amin = 10.0f * (float)std::log10((double)p.amin); a.chroma = p.chroma ? 1 : 0;
+  a.parity = p.parity ? 1 : 0; a.t_max = (int)t_max;
+  a.window64 = pcm_type == DYSF_PCM_I16 ? h->d_window64_i16 : h->d_window64; a.stage_tw64 = h->d_stage_tw64; a.post_tw64 = h->d_post_tw64;
   a.window = h->d_window; a.window_i16 = h->d_window_i16; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_groups = t.dct_groups;
   a.dct_pack32 = h->dct64 ? nullptr : h->d_dct_pack32; a.dct_rowsum = h->d_dct_rowsum; a.inv_n_mels = 1.0f / (float)p.n_mels;
-  a.chroma_pack = h->d_chroma_pack; a.chroma_steps = t.chroma_steps;
+  a.chroma_pack = h->d_chroma_pack; a.chroma_groups = t.chroma_groups;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
 
   // ---- kernel A geometry: small workgroups, several per CU
   const int nt_a = stft_threads(t.NC), nw_a = nt_a / 64;
   const int fpi_a = t.FPW * nw_a, cb_a = (fpi_a + 15) / 16;
-  int rstride = std::max(t.FPW * (t.NC + t.NC / 16), t.FPW * t.kpad);
+  // per-wave LDS region: FFT exchange buffers (doubles in the parity presets), later the power-spectrum rows
+  int rstride = std::max(t.FPW * (t.NC + t.NC / 16) * (p.parity ? 2 : 1), t.FPW * t.kpad);
   while (rstride % 32 != 8) ++rstride;
   a.rstride = rstride;
   if (!h->sched_built) {
@@ -313,10 +328,11 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.peak_tile_cap = p.chroma ? fpi_a * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   a.ws_peak_stride = p.chroma ? t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * t.L + 3) & ~3;
+  const int tables_a = p.parity ? 0 : tables;  // the float64 tables of the parity presets are read from L2
   const int tile_a = ((fpi_a - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 2 * a.peak_tile_cap + 3) & ~3;
   const int lds_a_region = 0, lds_a_pcm = nw_a * rstride, lds_a_misc = lds_a_pcm + tile_a, lds_a_tables = lds_a_misc + misc_a;
-  size_t lds_a = (size_t)(lds_a_tables + tables) * 4;
+  size_t lds_a = (size_t)(lds_a_tables + tables_a) * 4;
   if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
   if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
 
@@ -324,10 +340,12 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int nw_c = 8, fpi_c = t.FPW * nw_c, cb_c = (fpi_c + 15) / 16;
   const int tile_c = ((fpi_c - 1) * p.hop + p.n_fft + 8 + 7) & ~7;
   const int misc_c = (128 + nw_c * cb_c * 256 + 16 * cb_c * 16 + 3) & ~3;
-  const int lds_c_pcm = nw_c * rstride, lds_c_misc = lds_c_pcm + tile_c, lds_c_tables = lds_c_misc + misc_c;
+  int rstride_c = std::max(t.FPW * (t.NC + t.NC / 16), t.FPW * t.kpad);  // kernel D keeps the float32 FFT
+  while (rstride_c % 32 != 8) ++rstride_c;
+  const int lds_c_pcm = nw_c * rstride_c, lds_c_misc = lds_c_pcm + tile_c, lds_c_tables = lds_c_misc + misc_c;
   const size_t lds_c = (size_t)(lds_c_tables + tables) * 4;
-  if ((p.chroma || p.rich) && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
-  if (p.rich && (size_t)nw_c * rstride * 4 < (size_t)kRichSegBytes) return fail(DYSF_E_INVALID, "LDS regions too small for the rich preset");
+  if (p.rich && lds_c > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+  if (p.rich && (size_t)nw_c * rstride_c * 4 < (size_t)kRichSegBytes) return fail(DYSF_E_INVALID, "LDS regions too small for the rich preset");
 
   // ---- kernel B LDS: frame-0 features, float64 DCT operands, MFCC chunk (the final reduction reuses the last two)
   const int nd = t.dct_pack.row_blocks * t.dct_groups * 256;
@@ -336,8 +354,14 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   // ---- per-clip workspace; very large batches run as several sub-batches that reuse it
   a.ws_rich_stride = p.rich ? t_max : 0;
   a.rich_offset = 6 * p.n_mfcc + (p.chroma ? 2 * kChroma : 0); a.rich_fl = kRichFrameLength; a.rich_tab = h->d_rich_tab;
-  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4;
-  const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(h->ws_budget / per_clip)));
+  a.s_stride = p.chroma ? 16 * t.chroma_groups : 0;
+  a.ws_S_stride = p.chroma ? t_max * (int64_t)a.s_stride : 0;
+  const bool need_stat = p.parity && d_pooled && !d_frames;  // kernel B re-reads the frame rows for NumPy-order statistics
+  a.stat_stride = need_stat ? ((t_max + 3) & ~(int64_t)3) : 0;
+  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4 +
+                          (size_t)a.ws_S_stride * 4 + (size_t)a.stat_stride * 3 * p.n_mfcc * 4;
+  // a sub-batch is gridDim.y of kernel A: at most 65535 clips
+  const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_clips, 65535), (int64_t)(h->ws_budget / per_clip)));
   if (int rc = h->ws_logmel.reserve((size_t)sub * a.ws_logmel_stride * 4)) return rc;
   if ((size_t)sub * 12 > h->ws_small.cap) h->ws_clean = false;
   if (int rc = h->ws_small.reserve((size_t)sub * 12)) return rc;
@@ -346,6 +370,10 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     if (int rc = h->ws_peak_bin.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
   }
   if (p.rich) { if (int rc = h->ws_rich.reserve((size_t)sub * a.ws_rich_stride * 14 * 4)) return rc; }
+  if (p.chroma) { if (int rc = h->ws_S.reserve((size_t)sub * a.ws_S_stride * 4)) return rc; }
+  if (need_stat) { if (int rc = h->ws_stat.reserve((size_t)sub * a.stat_stride * 3 * p.n_mfcc * 4)) return rc; }
+  a.ws_S = (float*)h->ws_S.p;
+  a.ws_stat = (float*)h->ws_stat.p;
   a.ws_rich = (float*)h->ws_rich.p;
   a.ws_logmel = (float*)h->ws_logmel.p;
   a.ws_peak_mag = (float*)h->ws_peak_mag.p;
@@ -373,6 +401,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.self_clean = (p.chroma || p.rich) ? 0 : 1;  // (kernels C and D read the flag after kernel B)
     if (!(a.self_clean && h->ws_clean && h->ws_stream == stream)) HIPCHK(hipMemsetAsync(h->ws_small.p, 0, h->ws_small.cap, stream));
     h->ws_clean = false;
+    a.rstride = rstride;
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
     HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
@@ -380,11 +409,9 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
     h->ws_clean = a.self_clean != 0; h->ws_stream = stream;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[2], stream));
-    if (p.chroma) {
-      a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
-      HIPCHK(launch_chroma(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
-    }
+    if (p.chroma) HIPCHK(launch_chroma(a, dim3(nc), stream));
     if (p.rich) {
+      a.rstride = rstride_c;
       a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;
       HIPCHK(launch_rich(a, p.n_fft, pcm_type, dim3(nc), lds_c, stream));
     }

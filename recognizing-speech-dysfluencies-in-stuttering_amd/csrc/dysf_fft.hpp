@@ -27,19 +27,31 @@ constexpr int kChroma = 12;
 
 #if defined(__clang__)
 typedef float cf __attribute__((ext_vector_type(2)));
+typedef double cd __attribute__((ext_vector_type(2)));   // the parity presets run the same FFT in float64
 #define DYSF_SWAP(z) __builtin_shufflevector((z), (z), 1, 0)
 #else
 typedef float cf __attribute__((vector_size(8)));
+typedef double cd __attribute__((vector_size(16)));
 typedef int cf_mask_ __attribute__((vector_size(8)));
-#define DYSF_SWAP(z) __builtin_shuffle((z), (cf_mask_){1, 0})
+typedef long long cd_mask_ __attribute__((vector_size(16)));
+#define DYSF_SWAP(z) dysf_swap_(z)
+static inline cf dysf_swap_(cf z) { return __builtin_shuffle(z, (cf_mask_){1, 0}); }
+static inline cd dysf_swap_(cd z) { return __builtin_shuffle(z, (cd_mask_){1, 0}); }
 #endif
+
+template <class C> struct scalar_of;
+template <> struct scalar_of<cf> { typedef float type; };
+template <> struct scalar_of<cd> { typedef double type; };
 
 DYSF_HD cf mk(float re, float im) { cf r = {re, im}; return r; }
 // z * (-i) = (im, -re)
-DYSF_HD cf mul_mi(cf z) { cf s = DYSF_SWAP(z); cf r = {s[0], -s[1]}; return r; }
+template <class C>
+DYSF_HD C mul_mi(C z) { C s = DYSF_SWAP(z); C r = {s[0], -s[1]}; return r; }
 // z * (wr + i wi) with compile-time-constant twiddles: the (-wi, wi) vector is a literal
-DYSF_HD cf cmul_const(cf z, float wr, float wi) {
-  const cf a = {wr, wr}, b = {-wi, wi};
+template <class C>
+DYSF_HD C cmul_const(C z, double wr, double wi) {
+  typedef typename scalar_of<C>::type T;
+  const C a = {(T)wr, (T)wr}, b = {(T)-wi, (T)wi};
   return z * a + DYSF_SWAP(z) * b;
 }
 // z * w with a run-time twiddle held in a register pair
@@ -54,6 +66,10 @@ DYSF_HD cf cmul(cf z, cf w) {
   cf r = {z[0] * w[0] - z[1] * w[1], z[0] * w[1] + z[1] * w[0]};
   return r;
 #endif
+}
+DYSF_HD cd cmul(cd z, cd w) {
+  cd r = {z[0] * w[0] - z[1] * w[1], z[0] * w[1] + z[1] * w[0]};
+  return r;
 }
 
 // LDS exchange-buffer padding: one float of padding every 16 keeps the stride-16 writes of the first
@@ -75,19 +91,19 @@ struct FftGeom {
 };
 
 // ---- small DFTs on register arrays, elements at stride ST -------------------------------------
-template <int ST>
-DYSF_HD void dft2(cf* z) {
-  const cf a = z[0], b = z[ST];
+template <int ST, class C>
+DYSF_HD void dft2(C* z) {
+  const C a = z[0], b = z[ST];
   z[0] = a + b;
   z[ST] = a - b;
 }
 
 // forward radix-4: X[u] = sum_q x[q] (-i)^(q u)
-template <int ST>
-DYSF_HD void dft4(cf* z) {
-  const cf t0 = z[0] + z[2 * ST], t1 = z[0] - z[2 * ST];
-  const cf t2 = z[ST] + z[3 * ST], t3 = z[ST] - z[3 * ST];
-  const cf m = mul_mi(t3);
+template <int ST, class C>
+DYSF_HD void dft4(C* z) {
+  const C t0 = z[0] + z[2 * ST], t1 = z[0] - z[2 * ST];
+  const C t2 = z[ST] + z[3 * ST], t3 = z[ST] - z[3 * ST];
+  const C m = mul_mi(t3);
   z[0] = t0 + t2;
   z[ST] = t1 + m;       // t1 - i t3
   z[2 * ST] = t0 - t2;
@@ -96,10 +112,11 @@ DYSF_HD void dft4(cf* z) {
 
 // forward radix-16 on 16 contiguous registers, output in natural order.
 // n = q + 4p, k = s + 4u:  a[q][s] = sum_p x[q+4p] W4^(ps);  X[s+4u] = sum_q a[q][s] W16^(qs) W4^(qu).
-DYSF_HD void dft16(cf* z) {
-  constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
-  constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
-  constexpr float H = 0.70710678118654752440f;   // sqrt(1/2)
+template <class C>
+DYSF_HD void dft16(C* z) {
+  constexpr double C1 = 0.92387953251128675613;  // cos(pi/8)
+  constexpr double S1 = 0.38268343236508977173;  // sin(pi/8)
+  constexpr double H = 0.70710678118654752440;   // sqrt(1/2)
   // inner radix-4 over p for each q: elements q, q+4, q+8, q+12 (stride 4); result index s at q+4s
 #pragma unroll
   for (int q = 0; q < 4; ++q) dft4<4>(z + q);
@@ -121,14 +138,14 @@ DYSF_HD void dft16(cf* z) {
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int u = s + 1; u < 4; ++u) {
-      const cf t = z[4 * s + u]; z[4 * s + u] = z[4 * u + s]; z[4 * u + s] = t;
+      const C t = z[4 * s + u]; z[4 * s + u] = z[4 * u + s]; z[4 * u + s] = t;
     }
 }
 
 // One Stockham stage on a lane's 16 points.  Point p = b + NB*r belongs to butterfly b (NB = 16/R
 // butterflies per lane), input slot r.  tw[p] is the stage twiddle (ignored for stage 0).
-template <int NC, int S>
-DYSF_HD void fft_stage(cf* z, const cf* tw) {
+template <int NC, int S, class C>
+DYSF_HD void fft_stage(C* z, const C* tw) {
   constexpr int R = FftGeom<NC>::radix(S);
   constexpr int NB = kPts / R;
   if (S > 0) {
@@ -180,6 +197,16 @@ DYSF_HD void fft_twiddle_frac(int ls, int p, int* num, int* den) {
 // window table), so with Zk = Z[k], Zm = Z[(NC-k)%NC] and V = -i exp(-2 pi i k / (2 NC)) = (wi, -wr):
 //   X[k] = (Zk + conj Zm) + V (Zk - conj Zm),   X[NC-k] = conj((Zk + conj Zm) - V (Zk - conj Zm)).
 // Returns |X[k]|^2 and |X[NC-k]|^2.
+// float64 form used by the parity presets: the two spectrum values themselves (the caller rounds them to complex64)
+DYSF_HD void rfft_pair(cd zk, cd zm, cd v, cd* xk, cd* xm) {
+  const cd cm = {zm[0], -zm[1]};
+  const cd e = zk + cm, o = zk - cm;
+  const cd t = cmul(o, v);
+  const cd x = e + t, y = e - t;
+  *xk = x;
+  cd yc = {y[0], -y[1]};
+  *xm = yc;
+}
 DYSF_HD void rfft_pair_power(cf zk, cf zm, cf v, float* pk, float* pm) {
   const cf cm = {zm[0], -zm[1]};
   const cf e = zk + cm, o = zk - cm;

@@ -26,6 +26,8 @@ struct KArgs {
   int sr, hop, kpad, n_mels, n_mfcc;
   float top_db, amin, db_amin;
   int chroma;
+  int parity;        // 1: float64 FFT + NumPy's complex64 abs (kernel A), NumPy-order float32 statistics (kernel B)
+  int t_max;         // frames the workspace rows are sized for; a clip with more is rejected (DYSF_TOO_LONG)
   int rstride;       // floats per wave region (FFT exchange + power-spectrum rows)
   int tiles_per_wg;  // kernel A: consecutive frame tiles one workgroup processes
   // tables
@@ -33,6 +35,9 @@ struct KArgs {
   const float* window_i16;  // the same times 2^-15: int16 PCM is staged as unscaled integers
   const float* stage_tw;
   const float* post_tw;
+  const double* window64;   // parity presets: [n_fft] window / 2 (times 2^-15 for int16 PCM), float64
+  const double* stage_tw64; // [(nstage-1)][L][16][2] float64
+  const double* post_tw64;  // [NC/2+1][2] float64
   const float* mel_pack;
   const int* mel_sched;   // per wave kMelSchedStride ints (see below)
   int mel_slots;          // split-K partial tiles kept in LDS
@@ -42,7 +47,7 @@ struct KArgs {
   float inv_n_mels;
   int dct_rb, dct_groups;  // row blocks of 16 coefficients, K groups of 16 mels
   const float* chroma_pack;
-  int chroma_steps;
+  int chroma_groups;        // K groups of 16 bins in a bank = s_stride / 16
   // rich presets (kernel D)
   int rich_offset;          // first float of the rich descriptors in a pooled row
   int rich_fl;              // frame length of zero_crossing_rate / rms (2048)
@@ -54,7 +59,12 @@ struct KArgs {
   float* ws_logmel;            // [clip][T_max][lm_stride] log-mel (dB, un-clamped), frame-major
   long long ws_logmel_stride;  // floats per clip
   int lm_stride;               // floats per log-mel row = n_mels rounded up to 16
-  unsigned* ws_clipmax;        // [clip] order-preserving encoding of the clip's log-mel maximum (atomicMax)
+  unsigned* ws_clipmax;        // [clip] bits of the clip's largest mel power (non-negative floats order like their bits)
+  float* ws_S;                 // chroma presets: [clip][T_max][s_stride] power spectrogram (kernel A -> kernel C)
+  long long ws_S_stride;       // floats per clip
+  int s_stride;                // floats per spectrum row = n_bins rounded up to 16 (padding columns are zero)
+  float* ws_stat;              // parity presets without a frames output: [clip][3*n_mfcc][stat_stride] frame rows
+  long long stat_stride;
   int self_clean;           // kernel B zeroes ws_clipmax / ws_flags after reading them (presets without chroma)
   int* ws_flags;               // [clip] 1: non-finite sample seen
   int* ws_peak_cnt;            // [clip] piptrack peaks appended so far
@@ -73,6 +83,8 @@ constexpr int kRichDim = 17;                             // rich presets: 7 + 7 
 constexpr int kRichFrameLength = 2048;                   // librosa's default frame_length of zero_crossing_rate / rms
 constexpr int kRichSegBytes = 1024 * 16;                 // kernel D: LDS taken from the regions by its segment sums
 constexpr int kMfccCstr = 132;                           // kernel B: LDS row stride of the MFCC chunk (128 columns)
+constexpr int kPwMaxFrames = 16384;                      // kernel B: longest clip whose statistics follow NumPy's pairwise order
+constexpr int kPwProg = 2 * (kPwMaxFrames / 64 + 2);     // entries of the pairwise-summation program (leaves + adds)
 constexpr int kMfccHead = 144;                           // kernel B: frame-0 features ahead of the DCT operands
 
 // kernel A workgroup size: 16 frames per tile up to n_fft 1024, 8 frames at n_fft 2048
@@ -80,7 +92,7 @@ constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
-hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s);
 hipError_t launch_rich(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 
 }  // namespace dysf

@@ -40,6 +40,32 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Single IEEE float32 operations that the compiler may not contract into an fma (HIP compiles with
+// -ffp-contract=fast, and clang's __fadd_rn / __fmul_rn are plain operators; its __fsqrt_rn is the approximate
+// v_sqrt_f32).  Used wherever a NumPy float32 rounding sequence is reproduced step by step.
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double dadd_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ double dmul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }   // correctly rounded (hipcc default)
+__device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }        // correctly rounded (hipcc default)
+
 // ---------------------------------------------------------------------------------------------
 // PCM tile staging in two halves so the HBM latency hides under the previous tile's FFT:
 //   pcm_prefetch  issues 16-byte coalesced loads of the samples [s0, s0 + count) of a clip into registers
@@ -183,7 +209,7 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
     const cf x = {tile[frame_off + 2 * n], tile[frame_off + 2 * n + 1]};
     z[p] = x * *(const cf*)(win + 2 * n);
   }
-  fft_stage<NC, 0>(z, nullptr);
+  fft_stage<NC, 0>(z, (const cf*)nullptr);
   fft_exchange<NC, 0>(z, xb, ls);
   {
     cf t1[kPts];
@@ -250,6 +276,97 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
 }
 
 // ---------------------------------------------------------------------------------------------
+// Parity presets (KArgs::parity): the same wave FFT in float64.  librosa.stft multiplies the float32 frame by the
+// float64 window, transforms in float64 and stores complex64; _spectrogram then takes np.abs(D)**2.  A float64 FFT
+// of a different factorisation agrees with pocketfft's to ~1e-16 of the frame's largest value, so the complex64
+// roundings agree except for ~1e-8 of the strong bins -- and only strong bins take part in piptrack's decisions.
+template <int NC, int SPREV>
+__device__ __forceinline__ void fft_exchange64(cd* z, double* xb, int ls) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, SPREV>(ls, p))] = z[p][h];
+    wave_lds_sync();
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) z[p][h] = xb[pad_idx(fft_in_index<NC>(ls, p))];
+    wave_lds_sync();
+  }
+}
+
+// np.abs of one complex64 value as NumPy's SIMD loop computes it (loops_unary_complex.dispatch.c.src, FMA form):
+// larger * sqrt(fma(r, r, 1)) with r = smaller / larger, every step rounded to float32; then squared.
+__device__ __forceinline__ float cabs2_numpy(float re, float im) {
+  const float ar = fabsf(re), ai = fabsf(im);
+  const float lg = fmaxf(ar, ai), sm = fminf(ai, ar);
+  const float ratio = (lg > 0.f && lg < INFINITY) ? div_rn(sm, lg) : 0.f;
+  const float m = mul_rn(sqrt_rn(__builtin_fmaf(ratio, ratio, 1.0f)), lg);
+  return mul_rn(m, m);
+}
+
+template <int NC>
+__device__ __forceinline__ void wave_frame_power_exact(const float* tile, int frame_off, double* xb, float* srow,
+                                                       int ls, const KArgs& a) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L;
+  constexpr int LAST = G::NSTAGE - 1;
+  const cd* win = (const cd*)a.window64;
+  cd z[kPts];
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    const int n = ls + L * p;
+    const cd x = {(double)tile[frame_off + 2 * n], (double)tile[frame_off + 2 * n + 1]};
+    z[p] = x * win[n];  // one float64 rounding per sample, as numpy's float64(frame) * window
+  }
+  fft_stage<NC, 0>(z, (const cd*)nullptr);
+  fft_exchange64<NC, 0>(z, xb, ls);
+  {
+    cd t1[kPts];
+    const cd* tw = (const cd*)a.stage_tw64 + ls * kPts;
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) t1[p] = tw[p];
+    fft_stage<NC, 1>(z, t1);
+  }
+  if (G::NSTAGE == 3) {
+    fft_exchange64<NC, 1>(z, xb, ls);
+    cd t2[kPts];
+    const cd* tw = (const cd*)a.stage_tw64 + (size_t)L * kPts + ls * kPts;
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) t2[p] = tw[p];
+    fft_stage<NC, 2>(z, t2);
+  }
+  cd zk[9], zm[9];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, LAST>(ls, p))] = z[p][h];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = (i == 8) ? NC / 2 : ls + L * i;
+      zk[i][h] = xb[pad_idx(k)];
+      zm[i][h] = xb[pad_idx((NC - k) % NC)];
+    }
+    wave_lds_sync();
+  }
+  // the mel product reads up to 32 words past a row's last bin (mel_segment): the words between the rows and after the
+  // wave's last row still hold halves of doubles, which need not be finite floats
+  for (int k = NC + 1 + ls; k < a.kpad; k += L) srow[k] = 0.f;
+  for (int k = ls; k < 40; k += L) srow[a.kpad + k] = 0.f;  // (the next row's head is rewritten below by its own lanes)
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = (i == 8) ? NC / 2 : ls + L * i;
+    cd xk, xm;
+    rfft_pair(zk[i], zm[i], ((const cd*)a.post_tw64)[k], &xk, &xm);
+    if (i < 8 || ls == 0) {
+      srow[k] = cabs2_numpy((float)xk[0], (float)xk[1]);       // complex64 rounding, then |.|**2 in float32
+      srow[NC - k] = cabs2_numpy((float)xm[0], (float)xm[1]);
+    }
+  }
+  wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
 // piptrack on one power-spectrum row (the wave's own frame): append (mag, histogram bin) of every
 // local maximum above 0.1*max in [pip_kmin, pip_kmax) to the workgroup's peak list.
 template <int NC>
@@ -261,7 +378,7 @@ __device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool fram
   for (int k = ls; k <= NC; k += L) mx = fmaxf(mx, srow[k]);
 #pragma unroll
   for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  const float ref = __fmul_rn(0.1f, mx);
+  const float ref = mul_rn(0.1f, mx);
   const int lane = threadIdx.x & 63;
   const int span = a.pip_kmax - a.pip_kmin;
   // Peaks are sparse (a few per 64 bins) and the interpolation below is float64-heavy, so a lane parks its candidate
@@ -281,23 +398,23 @@ __device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool fram
       const int k = pk;
       const float x0 = px0, xm = pxm, x1 = px1;
       // numba-typed parabolic interpolation of librosa.piptrack (int literals promote to float64)
-      const float dsum = __fadd_rn(x1, xm), ddif = __fsub_rn(x1, xm);
+      const float dsum = add_rn(x1, xm), ddif = sub_rn(x1, xm);
       const double pa = (double)dsum - 2.0 * (double)x0;
       const double pb = (double)ddif / 2.0;
       const float shift = (fabs(pb) >= fabs(pa)) ? 0.f : (float)(-pb / pa);
-      const float avg = __fmul_rn(ddif, 0.5f);
-      const float mag = __fadd_rn(x0, __fmul_rn(__fmul_rn(0.5f, avg), shift));
+      const float avg = mul_rn(ddif, 0.5f);
+      const float mag = add_rn(x0, mul_rn(mul_rn(0.5f, avg), shift));
       const float pitch = (float)((((double)k + (double)shift) * (double)a.sr) / (double)(2 * NC));
       // pitch_tuning residual, float32 like numpy; log2 is correctly rounded via float64
-      const float octs = (float)log2((double)__fdiv_rn(pitch, 27.5f));
-      const float x12 = __fmul_rn(12.0f, octs);
+      const float octs = (float)log2((double)div_rn(pitch, 27.5f));
+      const float x12 = mul_rn(12.0f, octs);
       float r = x12 - floorf(x12);
-      if (r >= 0.5f) r = __fsub_rn(r, 1.0f);
+      if (r >= 0.5f) r = sub_rn(r, 1.0f);
       const double rd = (double)r;
       int b = (int)floor((rd + 0.5) * 100.0);
       b = b < 0 ? 0 : (b > 99 ? 99 : b);
-      while (b > 0 && rd < __dadd_rn(__dmul_rn((double)b, 0.01), -0.5)) --b;
-      while (b < 99 && rd >= __dadd_rn(__dmul_rn((double)(b + 1), 0.01), -0.5)) ++b;
+      while (b > 0 && rd < dadd_rn(dmul_rn((double)b, 0.01), -0.5)) --b;
+      while (b < 99 && rd >= dadd_rn(dmul_rn((double)(b + 1), 0.01), -0.5)) ++b;
       if (slot < peak_cap) { peak_mag[slot] = mag; peak_bin[slot] = b; }
     }
     pend = false;
@@ -384,15 +501,18 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   return acc0 + acc1;
 }
 
-// 10*log10(x) = log2(x) * 10*log10(2): v_log_f32 plus a two-term constant.  Cells at the amin floor take the
-// host-computed float32(10*log10(amin)) (-100 exactly for 1e-10) so that silent cells are exact.
+// librosa.power_to_db computes float32(10) * np.log10(x): two float32 roundings.  log10 = v_log_f32 (log2) times
+// log10(2) as a two-term constant (about 1 ulp); cells at the amin floor take the host-computed constant
+// (-100 exactly for 1e-10) so that silent cells are exact.
 __device__ __forceinline__ float power_to_db(float x, const KArgs& a) {
   const float l2 = __builtin_amdgcn_logf(x);
-  return (x <= a.amin) ? a.db_amin : fmaf(l2, 3.0102999566398120f - 3.01029992103576660f, l2 * 3.01029992103576660f);
+  const float lg = fmaf(l2, -1.432098883924482e-08f, l2 * 0.3010300099849701f);
+  return (x <= a.amin) ? a.db_amin : mul_rn(10.0f, lg);
 }
 
 // finished mel tile -> four consecutive mels of one frame per lane -> one 16-byte store into the frame-major
-// log-mel workspace [T][lm_stride]; running max over the real mels
+// log-mel workspace [T][lm_stride]; running max of the mel POWER (log10 is monotonic: kernel B turns the clip's largest
+// power into the exact float32 dB value the reference's clamp starts from)
 template <int FPI>
 __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const KArgs& a, float* lm, int f0, int T,
                                              int lane, float& lmax) {
@@ -403,23 +523,12 @@ __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const K
     float4 v;
     v.x = power_to_db(acc[0], a); v.y = power_to_db(acc[1], a); v.z = power_to_db(acc[2], a); v.w = power_to_db(acc[3], a);
     *(float4*)(lm + (size_t)t * a.lm_stride + m0) = v;
-    if (m0 + 0 < a.n_mels) lmax = fmaxf(lmax, v.x);
-    if (m0 + 1 < a.n_mels) lmax = fmaxf(lmax, v.y);
-    if (m0 + 2 < a.n_mels) lmax = fmaxf(lmax, v.z);
-    if (m0 + 3 < a.n_mels) lmax = fmaxf(lmax, v.w);
+    // rows past n_mels have all-zero taps (acc = 0), so the clip's largest mel power needs no row mask
+    lmax = fmaxf(fmaxf(lmax, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// order-preserving float <-> uint (for atomicMax on the clip's running log-mel maximum)
-__device__ __forceinline__ unsigned enc_ordered(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_ordered(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
 #ifdef DYSF_STAMP
 // diagnostic build only (make stamp): lane 0 of wave 0 adds the cycles since its previous stamp to slot i
 #define STAMP_INIT unsigned long long stamp_last = __builtin_readcyclecounter()
@@ -438,8 +547,8 @@ __device__ __forceinline__ float dec_ordered(unsigned u) {
 
 // =============================================================================================
 // Kernel A: PCM -> STFT power -> mel -> dB.  grid = (tile groups, clips); NT threads, NT/64 waves.
-template <int NC, int PCM, int NT>
-__global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(const KArgs a) {
+template <int NC, int PCM, int NT, bool EX>
+__global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_mel_kernel(const KArgs a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L, FPW = G::FPW;
   constexpr int NW = NT / 64;
@@ -463,14 +572,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   const long long n = a.offsets[clip + 1] - off;
   const int T = (int)(1 + n / a.hop);
   const int ti0 = blockIdx.x * a.tiles_per_wg;
-  if (n <= 0 || T < 9 || ti0 * FPI >= T) return;  // rejected clips and empty tile groups (uniform exit)
+  if (n <= 0 || T < 9 || T > a.t_max || ti0 * FPI >= T) return;  // rejected clips and empty tile groups (uniform exit)
   const int ntiles = min(a.tiles_per_wg, (T - ti0 * FPI + FPI - 1) / FPI);
 
   float* wregion = regions + wave * a.rstride;
   float* xb = wregion + q * G::XSTRIDE;
+  double* xb64 = (double*)wregion + q * G::XSTRIDE;  // EX: the exchange buffer holds doubles (rstride is sized for it)
   float* srow_own = wregion + q * a.kpad;
   FftTabs tb;
-  load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
+  if (!EX) load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);  // EX reads its float64 tables from L2
   // the mel product reads a few words past a spectrum row's last bin (see mel_segment): no stale LDS there
   for (int i = tid * 4; i < NW * a.rstride; i += NT * 4) *(float4*)(regions + i) = float4{0.f, 0.f, 0.f, 0.f};
   int* sched = imisc + 32;
@@ -483,12 +593,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   f32x4 pend = {0.f, 0.f, 0.f, 0.f};
   float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
 
-  float lmax = -INFINITY;
+  float lmax = 0.f;  // largest mel power seen by this thread
   bool bad = false;
   const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
   PcmStage<PCM> stage;
   const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
   const int n32 = (int)n, off_lo = (int)(off & (EPG - 1));
+  float* sdst = a.ws_S ? a.ws_S + (size_t)clip * a.ws_S_stride : nullptr;
   auto tile_geom = [&](int ti, int* r0, int* shift, int* ngroups) {
     const int s0 = ti * FPI * a.hop - NC;
     *r0 = pcm_tile_origin<PCM>(off_lo, s0);
@@ -510,8 +621,20 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
     }
     {
       const int fl = wave * FPW + q;  // frame within tile
-      wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
+      if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, a);
+      else wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
       if (a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
+      if (sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
+#pragma unroll
+        for (int qq = 0; qq < FPW; ++qq) {
+          const int t = f0 + wave * FPW + qq;
+          if (t < T) {
+            const float* src = wregion + qq * a.kpad;
+            float* dst = sdst + (size_t)t * a.s_stride;
+            for (int k = lane; k < a.s_stride; k += 64) dst[k] = (k <= NC) ? src[k] : 0.f;
+          }
+        }
+      }
     }
     STAMP(1);  // prefetch issue + FFT
     __syncthreads();  // S tile complete; every wave is done reading the PCM tile
@@ -571,7 +694,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
     }
   }
   STAMP(6);  // finisher epilogues
-  // clip-global maximum of the log-mel (for the top_db clamp) and the non-finite flag
+  // clip-global maximum of the mel power (for the top_db clamp) and the non-finite flag
   lmax = wave_max(lmax);
   if (lane == 0) misc[wave] = lmax;
   if (PCM == DYSF_PCM_F32 && bad) a.ws_flags[clip] = 1;
@@ -579,8 +702,38 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 2)) void dysf_stft_mel_kernel(
   if (tid == 0) {
     float m = misc[0];
     for (int w = 1; w < NW; ++w) m = fmaxf(m, misc[w]);
-    atomicMax(a.ws_clipmax + clip, enc_ordered(m));
+    atomicMax(a.ws_clipmax + clip, __float_as_uint(fmaxf(m, 0.f)));  // non-negative floats order like their bits
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NumPy's float32 pairwise summation (np.add.reduce over a contiguous axis, umath/loops_utils.h.src), the order
+// np.mean / np.std of pipeline1.py:220-221 sum in.  A block of n <= 128 values is summed by 8 strided accumulators
+// that are then combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and followed by the n % 8 tail; longer rows are halved
+// (left half rounded down to a multiple of 8) recursively.  Eight consecutive lanes play the accumulators of one row.
+// pass 0 sums x[i]; pass 1 sums float32(float32(x[i] - mean)**2) (np.std's intermediate array).
+__device__ __forceinline__ float pw_leaf(const float* x, int n, int j, int pass, float mean) {
+  auto el = [&](int i) -> float {
+    const float v = x[i];
+    if (!pass) return v;
+    const float d = sub_rn(v, mean);
+    return mul_rn(d, d);
+  };
+  float res;
+  if (n < 8) {
+    res = 0.f;
+    for (int i = 0; i < n; ++i) res = add_rn(res, el(i));
+    return res;
+  }
+  float r = el(j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) r = add_rn(r, el(i + j));
+  r = add_rn(r, __shfl_xor(r, 1));
+  r = add_rn(r, __shfl_xor(r, 2));
+  r = add_rn(r, __shfl_xor(r, 4));
+  res = r;
+  for (; i < n; ++i) res = add_rn(res, el(i));
+  return res;
 }
 
 // =============================================================================================
@@ -611,6 +764,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   int st = DYSF_OK;
   if (n <= 0) st = DYSF_EMPTY;
   else if (T < 9) st = DYSF_TOO_SHORT;
+  else if (T > a.t_max) st = DYSF_TOO_LONG;  // device entry point called with a max_samples below this clip's length
   else if (a.ws_flags[clip]) st = DYSF_NONFINITE;
   float* prow = a.pooled ? a.pooled + (size_t)clip * a.pooled_dim : nullptr;
   float* frow = a.frames ? a.frames + (size_t)clip * 3 * C * a.frame_stride : nullptr;
@@ -627,7 +781,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   }
   if (tid == 0 && a.tuning && !a.chroma) a.tuning[clip] = 50;
   const float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
-  const float clip_max = dec_ordered(a.ws_clipmax[clip]);
+  // the clamp starts from float32(10) * float32(log10(largest mel power)): log10 correctly rounded through float64,
+  // then the float32 multiply -- the two roundings of librosa.power_to_db.  One ulp here moves every clamped cell.
+  const float xmax = __uint_as_float(a.ws_clipmax[clip]);
+  const float clip_max = (xmax <= a.amin) ? a.db_amin : mul_rn(10.0f, (float)log10((double)xmax));
   const float floor_db = (a.top_db >= 0.f) ? clip_max - a.top_db : -INFINITY;
   if (a.dbg_logmel)
     for (int i = tid; i < T * a.n_mels; i += NT) a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.lm_stride + (i % a.n_mels)];
@@ -644,6 +801,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   } else {
     for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
   }
+  // parity presets: the frame rows are kept (in the caller's frames output, else in the workspace stash) and summed
+  // again in NumPy's order at the end
+  float* wrow = frow;
+  long long wstr = a.frame_stride;
+  if (!wrow && a.parity && prow) { wrow = a.ws_stat + (size_t)clip * 3 * C * a.stat_stride; wstr = a.stat_stride; }
   float ps[RPW][6];
 #pragma unroll
   for (int i = 0; i < RPW; ++i)
@@ -797,10 +959,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
             const float e0 = x - kshift[c * 3 + 0], e1 = d - kshift[c * 3 + 1], e2 = dd - kshift[c * 3 + 2];
             ps[i][0] += e0; ps[i][1] += e1; ps[i][2] += e2;
             ps[i][3] += e0 * e0; ps[i][4] += e1 * e1; ps[i][5] += e2 * e2;
-            if (frow) {
-              frow[(size_t)c * a.frame_stride + t] = x;
-              frow[(size_t)(C + c) * a.frame_stride + t] = d;
-              frow[(size_t)(2 * C + c) * a.frame_stride + t] = dd;
+            if (wrow) {
+              wrow[(size_t)c * wstr + t] = x;
+              wrow[(size_t)(C + c) * wstr + t] = d;
+              wrow[(size_t)(2 * C + c) * wstr + t] = dd;
             }
           }
         }
@@ -813,7 +975,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     for (int i = tid; i < 3 * C * padc; i += NT) frow[(size_t)(i / padc) * a.frame_stride + T + (i % padc)] = 0.f;
   }
   __syncthreads();  // every wave is done with the MFCC chunk and the DCT operands: the scratch below reuses them
-  if (prow) {
+  const bool np_stats = a.parity && prow && T <= kPwMaxFrames;  // statistics in NumPy's summation order (below)
+  if (prow && !np_stats) {
     // Cross-lane totals without shuffles: per round the wave parks 18 quantities x 64 lanes in LDS, lane q sums
     // row q in float64 (conflict-free stride 65), lanes with a sum / sum-of-squares pair finish mean and std.
     float* scr = lds + kBDct + wave * (18 * 65 + 3);
@@ -843,60 +1006,100 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     }
   }
   STAMP(13);  // final reduction
+  if (np_stats) {
+    // np.mean / np.std in NumPy's own float32 summation order (clips beyond kPwMaxFrames keep the float64 statistics).
+    __syncthreads();  // scratch is free; every frame-row store of this workgroup has been issued and waited for
+    int2* prog = (int2*)(lds + kBDct);          // post-order program: (start, len) = push the leaf's sum; (0, 0) = add the top two
+    int* bstack = (int*)(prog + kPwProg);       // [40][3] thread 0's build stack
+    float* vstack = (float*)(bstack + 120);     // [NT / 8][16] value stacks
+    int* plen = (int*)(vstack + (NT / 8) * 16);
+    if (tid == 0) {
+      int np_ = 0, sp = 1;
+      bstack[0] = 0; bstack[1] = T; bstack[2] = 0;
+      while (sp > 0) {
+        int* e = bstack + 3 * (sp - 1);
+        const int s0 = e[0], ln = e[1];
+        if (ln <= 128) { prog[np_++] = make_int2(s0, ln); --sp; }
+        else if (e[2] == 0) {
+          e[2] = 1;
+          int n2 = ln / 2;
+          n2 -= n2 % 8;
+          int* rr = bstack + 3 * sp;       // right half below the left one: the left is summed first
+          rr[0] = s0 + n2; rr[1] = ln - n2; rr[2] = 0;
+          rr[3] = s0; rr[4] = n2; rr[5] = 0;
+          sp += 2;
+        } else { prog[np_++] = make_int2(0, 0); --sp; }
+      }
+      *plen = np_;
+    }
+    __syncthreads();
+    const int nprog = *plen;
+    const int j = tid & 7;
+    float* vs = vstack + (tid >> 3) * 16;
+    const float fT = (float)T;
+    for (int r = tid >> 3; r < 3 * C; r += NT / 8) {
+      const float* x = wrow + (size_t)r * wstr;
+      float mean = 0.f, sd = 0.f;
+      for (int pass = 0; pass < 2; ++pass) {
+        int sp = 0;
+        for (int e = 0; e < nprog; ++e) {
+          const int2 pe = prog[e];
+          float v;
+          if (pe.y == 0) { sp -= 2; v = add_rn(vs[sp], vs[sp + 1]); }
+          else v = pw_leaf(x + pe.x, pe.y, j, pass, mean);
+          wave_lds_sync();
+          vs[sp++] = v;
+          wave_lds_sync();
+        }
+        const float tot = vs[0];
+        if (pass == 0) mean = div_rn(tot, fT); else sd = sqrt_rn(div_rn(tot, fT));
+      }
+      if (j == 0) {
+        const int blk = r / C, c = r % C;
+        prow[blk * 2 * C + c] = mean;
+        prow[blk * 2 * C + C + c] = sd;
+      }
+    }
+  }
 }
 
 // =============================================================================================
-// Kernel C (chroma presets): tuning decision from the clip's peak list, second STFT pass, chroma GEMM, max-norm,
-// mean / std.  One workgroup per clip.
-template <int NC, int PCM, int NT>
-__global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
-  using G = FftGeom<NC>;
-  constexpr int L = G::L, FPW = G::FPW;
+// Kernel C (chroma presets): tuning decision from the clip's peak list (librosa.estimate_tuning), then
+// chroma = bank[tuning] x S over the power spectrogram kernel A left in the workspace, per-frame max-norm, mean / std
+// (librosa.feature.chroma_stft + pipeline1.py:228).  One workgroup per clip; a wave owns 16-frame column blocks and
+// streams their spectrum rows straight from HBM into MFMA B operands (16 bytes per lane, eight loads in flight):
+// K is walked in groups of 16 bins, lane (frame = l & 15, q = l >> 4) holding the four consecutive bins 16g + 4q + s,
+// and the bank pack has the same order ([tuning][group][lane][4]), so there is no LDS staging and no second FFT.
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
-  constexpr int FPI = FPW * NW;
-  constexpr int CB = (FPI + 15) / 16;
-  constexpr int EPG = PcmStage<PCM>::EPG;
-  extern __shared__ __align__(16) float lds[];
-  float* regions = lds + a.lds_region;
-  float* tile = lds + a.lds_pcm;
-  float* misc = lds + a.lds_misc;  // [0] scratch (int), [16..115] histogram (int), [128..] chroma partial tiles
-  int* imisc = (int*)misc;
+  __shared__ int sm_i[400];                    // [0..1] select control, [16..115] tuning histogram, [128..383] radix histogram
+  __shared__ double sm_red[NW * kChroma * 2];  // per-wave partial sums of the chroma rows
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave bases stay in SGPRs
-  const int q = lane / L;
-  // odd frames of a wave take their FFT lane roles rotated by L/2: the two frames that share a 32-lane LDS access
-  // group then read the PCM tile 16 banks apart (frames are a multiple of 32 banks apart whenever hop % 32 == 0)
-  const int ls = (FPW == 4) ? ((lane + ((q & 1) ? L / 2 : 0)) % L) : lane % L;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
   const long long off = a.offsets[clip];
   const long long n = a.offsets[clip + 1] - off;
   const int T = (int)(1 + n / a.hop);
-  if (n <= 0 || T < 9 || a.ws_flags[clip] || !a.pooled) {  // rejected clip: kernel B already wrote the zero row
+  if (n <= 0 || T < 9 || T > a.t_max || a.ws_flags[clip]) {  // rejected clip: kernel B already wrote the zero row
     if (tid == 0 && a.tuning) a.tuning[clip] = 50;
     return;
   }
-  float* wregion = regions + wave * a.rstride;
-  float* xb = wregion + q * G::XSTRIDE;
-  float* srow_own = wregion + q * a.kpad;
-  FftTabs tb;
-  load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
-  float* prow = a.pooled + (size_t)clip * a.pooled_dim;
   const float* pk_mag = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
   const int* pk_bin = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
-  int* hist = imisc + 16;
+  int* hist = sm_i + 16;
   int npk = a.ws_peak_cnt[clip];
   npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
-  __syncthreads();
   int tune = 50;
   if (npk > 0) {
     float thr;
     if (npk & 1) {
-      thr = block_select<NT>(pk_mag, npk, npk / 2, (int*)(misc + 128), &imisc[0]);
+      thr = block_select<NT>(pk_mag, npk, npk / 2, sm_i + 128, sm_i);
     } else {
-      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, (int*)(misc + 128), &imisc[0]);
-      const float hi = block_select<NT>(pk_mag, npk, npk / 2, (int*)(misc + 128), &imisc[0]);
-      thr = __fmul_rn(__fadd_rn(lo, hi), 0.5f);
+      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, sm_i + 128, sm_i);
+      const float hi = block_select<NT>(pk_mag, npk, npk / 2, sm_i + 128, sm_i);
+      thr = mul_rn(add_rn(lo, hi), 0.5f);
     }
     if (tid < kTunings) hist[tid] = 0;
     __syncthreads();
@@ -909,90 +1112,62 @@ __global__ __launch_bounds__(NT, 2) void dysf_chroma_kernel(const KArgs a) {
     tune = best;
   }
   if (tid == 0 && a.tuning) a.tuning[clip] = tune;
-  __syncthreads();
+  if (!a.pooled) return;
 
-  // second STFT pass + chroma GEMM (12 x n_bins bank, K split over the waves)
-  float* part = misc + 128;             // [NW][CB][16 rows][16 cols]
-  float* raw = part + NW * CB * 256;    // [16][CB*16]
-  const float* bank = a.chroma_pack + (size_t)tune * a.chroma_steps * 64;
-  double cs1 = 0.0, cs2 = 0.0;  // lane c < 12 of wave 0 accumulates chroma row c
-  float cshift = 0.f;
-  const int ntiles = (T + FPI - 1) / FPI;
-  const int tile_samples = (FPI - 1) * a.hop + 2 * NC;
-  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
-  const int n32 = (int)n, off_lo = (int)(off & (EPG - 1));
-  for (int ti = 0; ti < ntiles; ++ti) {
-    const int f0 = ti * FPI;
-    const int cs0 = f0 * a.hop - NC;
-    const int cr0 = pcm_tile_origin<PCM>(off_lo, cs0);
-    {
-      PcmStage<PCM> stage;
-      const int cng = (cs0 + tile_samples - cr0 + EPG - 1) / EPG;
-      pcm_prefetch<PCM, NT>(stage, pbase, n32, cr0, cng);
-      pcm_commit<PCM, NT>(stage, tile, pbase, n32, cr0, cng);
-    }
-    __syncthreads();
-    wave_frame_power<NC>(tile + (cs0 - cr0), (wave * FPW + q) * a.hop, xb, srow_own, ls, tb, a);
-    __syncthreads();
-    const int sb = (a.chroma_steps * wave) / NW, se = (a.chroma_steps * (wave + 1)) / NW;
-    for (int cb = 0; cb < CB; ++cb) {
-      int f = cb * 16 + (lane & 15);
-      f = f < FPI ? f : FPI - 1;
-      const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      int s = sb;
-      for (; s + 8 <= se; s += 8) {
-        float av[8], bv[8];
+  const float* bank = a.chroma_pack + (size_t)tune * a.chroma_groups * 256 + lane * 4;
+  const float* S = a.ws_S + (size_t)clip * a.ws_S_stride;
+  const int ncb = (T + 15) / 16;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int cb = wave; cb < ncb; cb += NW) {
+    const int t = cb * 16 + (lane & 15);
+    const float* srow = S + (size_t)(t < T ? t : T - 1) * a.s_stride + 4 * (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < a.chroma_groups; g0 += 8) {
+      float4 av[8], bv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = bank[(s + u) * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = 4 * (s + u) + (lane >> 4);
-          bv[u] = (k <= NC) ? srow[k] : 0.f;
+      for (int u = 0; u < 8; ++u)
+        if (g0 + u < a.chroma_groups) {
+          bv[u] = *(const float4*)(srow + 16 * (g0 + u));
+          av[u] = *(const float4*)(bank + (size_t)(g0 + u) * 256);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-      }
-      for (; s < se; ++s) {
-        const int k = 4 * s + (lane >> 4);
-        const float bv = (k <= NC) ? srow[k] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bank[s * 64 + lane], bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        part[((wave * CB + cb) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
-    }
-    __syncthreads();
-    for (int i = tid; i < CB * 256; i += NT) {
-      const int cb = i / 256, rc = i % 256;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += part[(w * CB + cb) * 256 + rc];
-      raw[(rc / 16) * (CB * 16) + cb * 16 + (rc % 16)] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      // lane c (< 12) walks the tile's frames in order; every lane computes the frame max
-      for (int f = 0; f < FPI && f0 + f < T; ++f) {
-        float mxv = 0.f;
-#pragma unroll
-        for (int c = 0; c < kChroma; ++c) mxv = fmaxf(mxv, fabsf(raw[c * (CB * 16) + f]));
-        const float len = (mxv < 1.17549435e-38f) ? 1.0f : mxv;
-        if (lane < kChroma) {
-          const float v = __fdiv_rn(raw[lane * (CB * 16) + f], len);
-          if (f0 + f == 0) cshift = v;
-          const double e = (double)v - (double)cshift;
-          cs1 += e; cs2 += e * e;
+      for (int u = 0; u < 8; ++u)
+        if (g0 + u < a.chroma_groups) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc, 0, 0, 0);
         }
+    }
+    // acc[r] = chroma row 4 * (lane >> 4) + r of frame t (rows 12..15 are padding: zero taps).  librosa.util.normalize
+    // with norm=inf: divide the frame by its largest magnitude unless that is below float32 tiny.
+    float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float len = (mx < 1.17549435e-38f) ? 1.0f : mx;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = (double)div_rn(acc[r], len);
+        s1[r] += v; s2[r] += v * v;
       }
     }
-    // the next staging barrier protects raw/part and the S regions
   }
-  if (wave == 0 && lane < kChroma) {
-    const double m1 = cs1 / (double)T, m2 = cs2 / (double)T;
-    const double var = m2 - m1 * m1;
-    prow[6 * C + lane] = (float)((double)cshift + m1);
-    prow[6 * C + kChroma + lane] = (float)sqrt(var > 0.0 ? var : 0.0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o); s2[r] += __shfl_xor(s2[r], o); }
+    const int row = 4 * (lane >> 4) + r;
+    if ((lane & 15) == 0 && row < kChroma) { sm_red[(wave * kChroma + row) * 2] = s1[r]; sm_red[(wave * kChroma + row) * 2 + 1] = s2[r]; }
+  }
+  __syncthreads();
+  if (tid < kChroma) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < NW; ++w) { t1 += sm_red[(w * kChroma + tid) * 2]; t2 += sm_red[(w * kChroma + tid) * 2 + 1]; }
+    const double m1 = t1 / (double)T, var = t2 / (double)T - m1 * m1;
+    float* prow = a.pooled + (size_t)clip * a.pooled_dim;
+    prow[6 * C + tid] = (float)m1;
+    prow[6 * C + kChroma + tid] = (float)sqrt(var > 0.0 ? var : 0.0);
   }
 }
 
@@ -1071,7 +1246,7 @@ __global__ __launch_bounds__(NT, 2) void dysf_rich_kernel(const KArgs a) {
     {  // spectral centroid: sum_k f_k |X_k| / sum_k |X_k|
       double s0 = 0.0, s1 = 0.0;
       for (int k = li; k <= NC; k += L) {
-        const float m = __fsqrt_rn(srow[k]);
+        const float m = sqrt_rn(srow[k]);
         s0 += (double)m; s1 += (double)m * (double)k;
       }
 #pragma unroll
@@ -1087,7 +1262,7 @@ __global__ __launch_bounds__(NT, 2) void dysf_rich_kernel(const KArgs a) {
         float bv = INFINITY, tv = -INFINITY;
         int bk = 0x7fffffff, tk = -1;
         for (int k = lo + li; k < hi; k += L) {
-          const float m = __fsqrt_rn(srow[k]);
+          const float m = sqrt_rn(srow[k]);
           if ((m > lv || (m == lv && k > lk)) && (m < bv || (m == bv && k < bk))) { bv = m; bk = k; }
           if ((m < hv || (m == hv && k < hk)) && (m > tv || (m == tv && k > tk))) { tv = m; tk = k; }
         }
@@ -1183,7 +1358,7 @@ __global__ __launch_bounds__(NT, 2) void dysf_rich_kernel(const KArgs a) {
         int zc = -seg_first[f];                        // a frame's first sample has no predecessor inside the frame
         for (int r = 0; r < R; ++r) { sq += seg_sq[f + r]; zc += seg_zc[f + r]; }
         zsum += (double)zc / (double)FL;
-        rsum += (double)__fsqrt_rn((float)(sq / (double)FL));
+        rsum += (double)sqrt_rn((float)(sq / (double)FL));
       }
     }
   }
@@ -1218,13 +1393,12 @@ static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, h
 template <int NC>
 static hipError_t launch_stft_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   constexpr int NT = stft_threads(NC);
-  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT>, grid, NT, lds_bytes, s, a);
-  return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT>, grid, NT, lds_bytes, s, a);
-}
-template <int NC>
-static hipError_t launch_chroma_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_I16, 512>, grid, 512, lds_bytes, s, a);
-  return launch_one(dysf_chroma_kernel<NC, DYSF_PCM_F32, 512>, grid, 512, lds_bytes, s, a);
+  if (a.parity) {
+    if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, true>, grid, NT, lds_bytes, s, a);
+    return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, true>, grid, NT, lds_bytes, s, a);
+  }
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, false>, grid, NT, lds_bytes, s, a);
+  return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, false>, grid, NT, lds_bytes, s, a);
 }
 
 template <int NC>
@@ -1258,14 +1432,9 @@ hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t 
   if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
   return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);
 }
-hipError_t launch_chroma(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  switch (n_fft) {
-    case 256: return launch_chroma_nc<128>(a, pcm_type, grid, lds_bytes, s);
-    case 512: return launch_chroma_nc<256>(a, pcm_type, grid, lds_bytes, s);
-    case 1024: return launch_chroma_nc<512>(a, pcm_type, grid, lds_bytes, s);
-    case 2048: return launch_chroma_nc<1024>(a, pcm_type, grid, lds_bytes, s);
-    default: return hipErrorInvalidValue;
-  }
+hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(dysf_chroma_kernel<512>, grid, dim3(512), 0, s, a);
+  return hipGetLastError();
 }
 
 }  // namespace dysf

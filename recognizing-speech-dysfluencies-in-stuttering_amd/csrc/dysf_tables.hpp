@@ -70,8 +70,12 @@ struct HostTables {
   std::vector<double> dct_rowsum;  // [16 * row blocks] float64 sum over mels of every row's float32 coefficients
   int dct_groups = 0;               // groups of 16 mels = mpad / 16
   std::vector<int32_t> rich_tab;    // rich presets: [7][3] contrast bands (first bin, end bin, bins averaged per end)
-  std::vector<float> chroma_pack;  // [100][chroma_steps*64]
-  int chroma_steps = 0;
+  std::vector<float> chroma_pack;  // [100][chroma_groups][64 lanes][4]: lane (row = l & 15, q = l >> 4) holds bins 16g + 4q + s
+  int chroma_groups = 0;           // ceil(n_bins / 16); spectrum rows in the workspace are 16 * chroma_groups floats
+  // parity presets: the FFT tables in float64
+  std::vector<double> window64_half;  // [n_fft] window / 2
+  std::vector<double> stage_tw64;     // [(nstage-1)][L][16][2]
+  std::vector<double> post_tw64;      // [NC/2+1][2]
   int pip_kmin = 0, pip_kmax = 0;  // piptrack bins with 150 <= f < min(4000, sr/2)
 };
 
@@ -97,7 +101,7 @@ inline std::vector<double> linspace(double start, double stop, int num, bool end
 inline double tuning_value(int idx) { return (double)idx * 0.01 + (-0.5); }
 
 template <int NC, int S>
-inline void fill_stage_tw(float* dst) {
+inline void fill_stage_tw(float* dst, double* dst64) {
   constexpr int L = FftGeom<NC>::L;
   for (int ls = 0; ls < L; ++ls)
     for (int p = 0; p < kPts; ++p) {
@@ -107,6 +111,8 @@ inline void fill_stage_tw(float* dst) {
       const double a = -2.0 * M_PI * (double)num / (double)den;
       dst[(ls * kPts + p) * 2 + 0] = (float)std::cos(a);
       dst[(ls * kPts + p) * 2 + 1] = (float)std::sin(a);
+      dst64[(ls * kPts + p) * 2 + 0] = std::cos(a);
+      dst64[(ls * kPts + p) * 2 + 1] = std::sin(a);
     }
 }
 template <int NC>
@@ -114,14 +120,18 @@ inline void fill_fft_tables(HostTables& t) {
   using G = FftGeom<NC>;
   t.NC = NC; t.L = G::L; t.FPW = G::FPW; t.nstage = G::NSTAGE;
   t.stage_tw.assign((size_t)(G::NSTAGE - 1) * G::L * kPts * 2, 0.f);
-  fill_stage_tw<NC, 1>(t.stage_tw.data());
-  if (G::NSTAGE == 3) fill_stage_tw<NC, 2>(t.stage_tw.data() + (size_t)G::L * kPts * 2);
+  t.stage_tw64.assign(t.stage_tw.size(), 0.0);
+  fill_stage_tw<NC, 1>(t.stage_tw.data(), t.stage_tw64.data());
+  if (G::NSTAGE == 3) fill_stage_tw<NC, 2>(t.stage_tw.data() + (size_t)G::L * kPts * 2, t.stage_tw64.data() + (size_t)G::L * kPts * 2);
   t.post_tw.resize((NC / 2 + 1) * 2);
+  t.post_tw64.resize((NC / 2 + 1) * 2);
   for (int k = 0; k <= NC / 2; ++k) {
     const double a = -2.0 * M_PI * (double)k / (double)(2 * NC);
     // V[k] = -i exp(-2 pi i k / N) = (sin a, -cos a) with a = -2 pi k / N   (see rfft_pair_power)
     t.post_tw[2 * k] = (float)std::sin(a);
     t.post_tw[2 * k + 1] = (float)(-std::cos(a));
+    t.post_tw64[2 * k] = std::sin(a);
+    t.post_tw64[2 * k + 1] = -std::cos(a);
   }
 }
 
@@ -144,6 +154,7 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   if (p.delta_width != 9) { *err = "delta_width must be 9"; return false; }
   if (p.sr < 1) { *err = "sr must be positive"; return false; }
   if (!(p.amin > 0.f)) { *err = "amin must be positive"; return false; }
+  if (p.parity != 0 && p.parity != 1) { *err = "parity must be 0 or 1"; return false; }
   if (p.rich && (2048 % p.hop != 0)) { *err = "rich presets need a hop that divides 2048 (frame_length of zcr / rms)"; return false; }
   if (p.rich && 6400.0 >= 0.5 * p.sr) { *err = "rich presets need sr > 12800 Hz (spectral_contrast bands)"; return false; }
   const int n_fft = p.n_fft, sr = p.sr;
@@ -162,6 +173,8 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   for (int n = 0; n < n_fft; ++n) t.window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)n_fft));
   t.window_half.resize(n_fft);
   for (int n = 0; n < n_fft; ++n) t.window_half[n] = 0.5f * t.window[n];
+  t.window64_half.resize(n_fft);  // the float64 window librosa.stft multiplies the frames by (scipy get_window), halved
+  for (int n = 0; n < n_fft; ++n) t.window64_half[n] = 0.5 * (0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)n_fft));
 
   // np.fft.rfftfreq(n_fft, 1/sr)
   const double val = 1.0 / ((double)n_fft * (1.0 / (double)sr));
@@ -256,8 +269,8 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
   if (p.chroma) {
     const int nc = kChroma;
     t.chroma.assign((size_t)kTunings * nc * t.n_bins, 0.f);
-    t.chroma_steps = (t.n_bins + 3) / 4;
-    t.chroma_pack.assign((size_t)kTunings * t.chroma_steps * 64, 0.f);
+    t.chroma_groups = (t.n_bins + 15) / 16;
+    t.chroma_pack.assign((size_t)kTunings * t.chroma_groups * 256, 0.f);
     std::vector<double> freqs = linspace(0.0, (double)sr, n_fft, false);
     std::vector<double> frq(n_fft), bw(n_fft), col(nc);
     std::vector<float> bank((size_t)nc * t.n_bins);
@@ -288,8 +301,13 @@ inline bool build_tables(const DysfParams& p, HostTables& t, const char** err) {
         }
       }
       std::copy(bank.begin(), bank.end(), t.chroma.begin() + (size_t)ti * nc * t.n_bins);
-      MfmaPack cp = pack_rows(bank, nc, t.n_bins, false);
-      std::copy(cp.data.begin(), cp.data.end(), t.chroma_pack.begin() + (size_t)ti * t.chroma_steps * 64);
+      float* cp = t.chroma_pack.data() + (size_t)ti * t.chroma_groups * 256;
+      for (int g = 0; g < t.chroma_groups; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int q = 0; q < 4; ++q) {
+            const int row = l & 15, k = 16 * g + 4 * (l >> 4) + q;
+            if (row < nc && k < t.n_bins) cp[((size_t)g * 64 + l) * 4 + q] = bank[(size_t)row * t.n_bins + k];
+          }
     }
   }
   return true;

@@ -26,6 +26,11 @@ class FeatureParams:
     delta_width: int = 9
     chroma: bool = True
     rich: bool = False         # main.py:738-754: + spectral-contrast mean/std (14), mean zcr, mean rms, mean centroid
+    # Reproduce the reference's rounding steps where they decide results (DysfParams.parity): float64 FFT rounded to
+    # complex64 + NumPy's complex abs (librosa.stft, p1:216/227), NumPy's pairwise float32 mean / std (p1:220-221).
+    # Needed for the tuning histogram of chroma_stft to follow the reference on every clip; False = float32 FFT,
+    # float64 statistics (the throughput path of the bench preset).
+    parity: bool = True
 
     @property
     def n_bins(self) -> int:
@@ -52,10 +57,11 @@ class FeatureParams:
         c.delta_width = self.delta_width
         c.chroma = 1 if self.chroma else 0
         c.rich = 1 if self.rich else 0
+        c.parity = 1 if self.parity else 0
         return c
 
 
 REFERENCE_149 = FeatureParams()
-BENCH_512 = FeatureParams(n_fft=512, hop=160, n_mels=64, n_mfcc=40, chroma=False)
+BENCH_512 = FeatureParams(n_fft=512, hop=160, n_mels=64, n_mfcc=40, chroma=False, parity=False)
 # main.py:621-630, 718-763 (main.py:628 evaluates to 281 audio + 5 text values, not the 329 of its comment)
 MAIN_286 = FeatureParams(n_fft=512, hop=256, n_mfcc=40, chroma=True, rich=True)

@@ -26,6 +26,11 @@ per_clip_audio = D[:, :120].max(axis=1)
 per_clip_chroma = D[:, 120:144].max(axis=1)
 # tuning index vs the oracle on the clips whose chroma block disagrees
 tun_mis = []
+# tuning index of EVERY clip against the oracle's (the histogram arg-max is a tie or near-tie in most clips)
+tun_all_equal = 0
+for i in range(len(clips)):
+    _, dbg = O.estimate_tuning(O.stft_power(O.pcm16_to_float(clips[i]), O.REFERENCE_149), O.REFERENCE_149)
+    tun_all_equal += int(res["tuning"][i] == dbg["index"])
 for i in np.nonzero(per_clip_chroma > 1e-4)[0]:
     _, dbg = O.estimate_tuning(O.stft_power(O.pcm16_to_float(clips[i]), O.REFERENCE_149), O.REFERENCE_149)
     tun_mis.append({"stem": idx[i]["stem"], "gpu_index": int(res["tuning"][i]), "oracle_index": int(dbg["index"]),
@@ -35,9 +40,13 @@ rec = {
     "n_pairs": len(clips), "all_status_ok": bool((res["status"] == 0).all()),
     "max_abs_diff": float(D.max()), "block_max_abs_diff": {k: float(D[:, a:b].max()) for k, (a, b) in blocks.items()},
     "mfcc_delta_blocks": {"max": float(per_clip_audio.max()), "p99": float(np.percentile(per_clip_audio, 99)),
-                          "median": float(np.median(per_clip_audio)), "n_over_1e-4": int((per_clip_audio > 1e-4).sum())},
+                          "median": float(np.median(per_clip_audio)), "n_over_1e-4": int((per_clip_audio > 1e-4).sum()),
+                          "n_over_6.2e-5": int((per_clip_audio > 6.2e-5).sum()),
+                          "clips_over_6.2e-5": [{"stem": idx[i]["stem"], "max_abs_diff": float(per_clip_audio[i]),
+                                                 "index": int(D[i, :120].argmax())} for i in np.nonzero(per_clip_audio > 6.2e-5)[0]]},
     "chroma_block": {"n_over_1e-4": int((per_clip_chroma > 1e-4).sum()), "median": float(np.median(per_clip_chroma)),
                      "clips_over_1e-4": tun_mis},
+    "tuning_index_equal_to_oracle": tun_all_equal,
     "n_clips_all_149_within_1e-4": int((D.max(axis=1) <= 1e-4).sum()),
 }
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
