@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- clips/s of the feature hot path on BASELINE.json configs[1], one process per GPU.
+"""bench.py -- clips/s of the feature hot path, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]                 (N > 1: starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                          (the driver's form: ranks come from the env)
 
-A step = one pass of the hot path over one resident batch: 1024 synthetic 3 s @ 16 kHz int16 clips ->
-512-pt STFT (hop 160) -> 64 Slaney mels -> dB (top_db 80) -> 40 MFCC + delta + delta-delta, written both as
-frame-level rows [1024, 120, 301] fp32 (the CNN input of configs[2]) and as pooled mean/std rows [1024, 240];
-then the pooled rows go through a small MLP head to per-clip logits and, for N > 1, the single collective of the
-path: an RCCL all-gather of the [1024, 3] logits.  Every rank owns its own 1024-clip shard (weak scaling); the
-PCM is already in HBM when the timed region starts.  Steps are independent batches, so they are submitted round-robin to
-`--lanes` HIP streams (rsd_amd.pipeline.LaneExecutor, default 3, each lane with its own extractor handle): the STFT kernel
-of one step overlaps the MFCC kernel / head / gather of the previous one.  All lanes are joined before the closing fence;
-`--lanes 1` is the strictly serial loop.  Ahead of the W warm-up steps the script issues 60 more untimed launches
-(first-use work of every lane, GPU clock ramp; `--no-preheat` skips them); the timed region is exactly K steps.
+Workloads (BASELINE.json `configs`):
+  default            configs[1]: per GPU 1024 synthetic 3 s @ 16 kHz int16 clips resident in HBM -> 512-pt STFT (hop 160)
+                     -> 64 Slaney mels -> dB (top_db 80) -> 40 MFCC + delta + delta-delta, written as frame-level rows
+                     [1024, 120, 301] fp32 and pooled mean/std rows [1024, 240]; pooled rows -> MLP head -> logits and,
+                     for N > 1, the single collective of the path: an RCCL all-gather of the [1024, 3] logits.  Weak
+                     scaling (every rank owns its own 1024-clip shard).
+  --head cnn         configs[2]: the same launch with the 2-layer CNN head (HIP kernels, MFMA) on the frame-level rows.
+  --config 4         configs[3]: 100 000 clips (clip j = bank clip j mod 1024) sharded contiguously over the ranks
+                     (12 500 per GPU at N = 8), resident; pooled rows -> MLP head -> one all-gather of [n_local, 3]; the
+                     gathered arg-max is checked against the single-GPU result of the bank.  Strong scaling.
+  --preset reference_149   the reference's own parameterisation (2048 / 512 / 128 mels / 20 MFCC + chroma, parity mode)
+                     on the same 1024 clips per GPU: pooled 144-d rows + tuning index -> MLP(149 -> 128 -> 64 -> 3).
 
-Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel (HIP-event timed on the
-launch stream) and, at N = 1, a `cpu_baseline` object (the NumPy oracle timed on the host cores on a bounded
-sample of the same clips).
+A step = one pass of the hot path over the rank's resident batch.  Steps are independent batches, so they alternate
+between `--lanes` HIP streams (rsd_amd.pipeline.LaneExecutor, default 3, one extractor handle each); all lanes are joined
+before the closing fence.  Exactly W untimed warm-up steps run first (no hidden extra launches), then K timed steps between
+barrier + synchronize fences; the slowest rank's wall time counts.
+
+Rank 0 prints ONE JSON line: the metric, a `roofline` object for the dominant kernel (durations from HIP events on the launch
+stream, bytes = SURVEY 8d's algorithmic figure, no intermediates) and, at N = 1, a `cpu_baseline` object (the NumPy oracle
+timed on the host cores on a bounded sample of the same clips) and the PCIe-inclusive rate from host memory.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,19 +40,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BATCH = 1024          # clips per GPU per step (BASELINE.json configs[1])
-N_SAMPLES = 48000     # 3 s @ 16 kHz
+BATCH = 1024           # clips per GPU per step (BASELINE.json configs[1])
+N_SAMPLES = 48000      # 3 s @ 16 kHz
+TOTAL_CONFIG4 = 100000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TF = 2500.0   # dense fp16 / bf16 MFMA
+MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA (= the fp32 vector rate)
+CSRC = os.path.join(ROOT, "recognizing-speech-dysfluencies-in-stuttering_amd", "csrc")
 
 
-def _cpu_worker(clip):
+def kernel_source_id():
+    """Short hash of the kernel sources: ties counter files under profiles/ to the build they were measured on."""
+    h = hashlib.sha256()
+    for name in ("dysf_kernels.hip", "dysf_fft.hpp", "dysf_kernels.h", "dysf_cnn.hip"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def _cpu_worker(job):
     from oracle import dysf_oracle as O
-    return O.frame_level_stack(O.pcm16_to_float(clip), O.BENCH_512).shape[1]
+    clip, preset = job
+    y = O.pcm16_to_float(clip)
+    if preset == "reference_149":
+        return O.extract_audio_features(y, 16000, O.REFERENCE_149).shape[0]
+    return O.frame_level_stack(y, O.BENCH_512).shape[1]
 
 
-def cpu_baseline(bank, budget_s=15.0):
+def cpu_baseline(bank, preset, budget_s=15.0):
     """Reported baseline only: the CPU oracle (a NumPy/SciPy port of the reference's librosa calls) on a bounded
-    sample of the same clips, one clip per task over all host cores available to this process."""
+    sample of the same clips, one clip per task over the host cores available to this process."""
     import multiprocessing as mp
 
     from threadpoolctl import threadpool_limits
@@ -52,14 +79,14 @@ def cpu_baseline(bank, budget_s=15.0):
         t0 = time.perf_counter()
         n1 = 0
         while n1 < 8 or time.perf_counter() - t0 < 2.0:
-            _cpu_worker(bank[n1 % len(bank)])
+            _cpu_worker((bank[n1 % len(bank)], preset))
             n1 += 1
         one = n1 / (time.perf_counter() - t0)
         sample = int(min(len(bank), max(cores * 4, one * cores * budget_s * 0.5)))
         with mp.get_context("fork").Pool(cores) as pool:
-            pool.map(_cpu_worker, [bank[i] for i in range(min(cores, len(bank)))])  # warm the workers
+            pool.map(_cpu_worker, [(bank[i], preset) for i in range(min(cores, len(bank)))])  # warm the workers
             t0 = time.perf_counter()
-            pool.map(_cpu_worker, [bank[i % len(bank)] for i in range(sample)], chunksize=4)
+            pool.map(_cpu_worker, [(bank[i % len(bank)], preset) for i in range(sample)], chunksize=4)
             dt = time.perf_counter() - t0
     model = ""
     try:
@@ -67,32 +94,66 @@ def cpu_baseline(bank, budget_s=15.0):
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
+    what = ("extract_audio_features (REFERENCE_149: 2048-pt STFT, 128 mels, 20 MFCC + deltas + chroma incl. the tuning estimate)"
+            if preset == "reference_149" else "frame_level_stack (BENCH_512)")
     return {"value": round(sample / dt, 2), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} clips of the same synthetic bank through oracle/dysf_oracle.py frame_level_stack "
-                      f"(BENCH_512), one clip per task, {cores} processes x 1 BLAS thread",
+            "sample": f"{sample} clips of the same synthetic bank through oracle/dysf_oracle.py {what}, one clip per task, "
+                      f"{cores} processes x 1 BLAS thread",
             "one_thread_clips_per_s": round(one, 2), "cpu_model": model}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 with --config 4)")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
+                    help="2 = BASELINE configs[1] (1024 clips per GPU, weak scaling); 4 = configs[3] (100k clips, strong scaling)")
+    ap.add_argument("--preset", default="bench_512", choices=("bench_512", "reference_149"))
+    ap.add_argument("--head", default="mlp", choices=("mlp", "cnn"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive measurement (N = 1 only)")
     ap.add_argument("--eager-head", action="store_true",
                     help="run the MLP head as the eager torch module instead of the one-kernel HIP head (dysf_mlp_*)")
-    ap.add_argument("--no-preheat", action="store_true", help="skip the 60 extra untimed launches ahead of the warm-up steps")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test aid: all ranks run on cuda:0 and the collective goes over gloo (never a measurement)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="HIP streams (and extractor handles) that consecutive batches alternate between; 1 = serial")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the step (feature launch + head) into a hipGraph and replay it; measured equal to eager "
-                         "launches on MI355X (the head's small GEMMs are GPU time, not launch overhead), so off by default")
     ap.add_argument("--bank-workers", type=int, default=0,
                     help="processes generating the synthetic bank (0 = auto; use 1 under rocprofv3 --pmc, which "
                          "initialises the GPU before main() and must not be followed by a fork)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start the N rank processes (fresh interpreters, nothing has touched
+    the GPU in this one), wait for them and pass on the first non-zero exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # a failed rank leaves the others in a collective: do not wait for their timeout
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if args.steps is None:
+        args.steps = 20 if args.config == 4 else 200
 
     import numpy as np
     import torch
@@ -100,8 +161,7 @@ def main():
 
     import rsd_amd
     from rsd_amd.classifier import FusedMLPHead, MLPHead
-    from rsd_amd.pipeline import LaneExecutor
-    from rsd_amd.pipeline import gather_rows
+    from rsd_amd.pipeline import LaneExecutor, gather_rows, shard_range
     from rsd_amd.synth import synth_bank
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,14 +170,15 @@ def main():
     if args.share_gpu:   # rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0, gloo carries the gather
         local_rank = 0
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # host-only work first (process pools fork; keep that ahead of any GPU initialisation):
-    # every rank owns an identical-size shard of the clip index space
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.head == "cnn" and (args.preset != "bench_512" or args.config != 2):
+        raise SystemExit("--head cnn runs on the frame-level rows of the default workload (configs[2])")
+    # host-only work first (process pools fork; keep that ahead of any GPU initialisation)
     workers = args.bank_workers or max(1, min(8, len(os.sched_getaffinity(0)) // max(1, world)))
     bank = synth_bank(BATCH, N_SAMPLES, 16000, workers=workers)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(bank[:256])
+        cpu = cpu_baseline(bank[:256], args.preset)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -127,108 +188,155 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    pcm = torch.from_numpy(bank.reshape(-1)).to(dev)
-    offsets = (torch.arange(0, BATCH + 1, dtype=torch.int64) * N_SAMPLES).to(dev)
 
-    params = rsd_amd.BENCH_512
+    bank_dev = torch.from_numpy(bank).to(dev)                      # [1024, 48000] int16
+    if args.config == 4:   # this rank's contiguous shard of the 100 000-clip index space, clip j = bank clip j mod 1024
+        total = TOTAL_CONFIG4
+        lo, hi = shard_range(total, rank, world)
+        n_local = hi - lo
+        pcm = bank_dev[(torch.arange(lo, hi, device=dev) % BATCH)].reshape(-1).contiguous()
+    else:
+        total = BATCH * world
+        lo, n_local = rank * BATCH, BATCH
+        pcm = bank_dev.reshape(-1)
+    offsets = (torch.arange(0, n_local + 1, dtype=torch.int64) * N_SAMPLES).to(dev)
+
+    params = rsd_amd.REFERENCE_149 if args.preset == "reference_149" else rsd_amd.BENCH_512
+    want_frames = args.preset == "bench_512" and args.config == 2
     ex = rsd_amd.FeatureExtractor(params, local_rank)
     T = params.n_frames(N_SAMPLES)
     rng = np.random.default_rng(0)
-    dims = [ex.pooled_dim, 128, 64, 3]
+    n_in = params.total_feature_len if args.preset == "reference_149" else ex.pooled_dim
+    dims = [n_in, 128, 64, 3]
     head_w = [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)]
     head_b = [np.zeros(dims[i + 1]) for i in range(3)]
-    if args.eager_head:   # the torch module (seven small launches); the default is the one-kernel HIP head
+    cnn = None
+    if args.head == "cnn":
+        from rsd_amd.classifier import CNNHead, FusedCNNHead
+        torch.manual_seed(0)
+        cnn = FusedCNNHead(CNNHead().to(dev))
+        head = None
+    elif args.eager_head:   # the torch module (seven small launches); the default is the one-kernel HIP head
         head = MLPHead(np.zeros(dims[0]), np.ones(dims[0]), head_w, head_b).to(dev)
     else:
         head = FusedMLPHead(np.zeros(dims[0]), np.ones(dims[0]), head_w, head_b, device=local_rank)
 
-    per_kernel = []  # HIP events the library records around each of its kernels (dysf_debug_timing)
+    def run_head(res):
+        if cnn is not None:
+            return cnn(res["frames"])
+        x = res["pooled"]
+        if x.shape[1] < n_in:   # the five always-zero text features (pipeline1.py:243-244)
+            x = torch.cat([x, x.new_zeros((x.shape[0], n_in - x.shape[1]))], dim=1)
+        return head(x)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Optional: the step (feature launch + head) captured once into a hipGraph and replayed; the all-gather of the
-    # logits (N > 1) stays an eager RCCL call after the replay.
-    graph = None
-    if args.graph:
-        try:
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.no_grad(), torch.cuda.stream(side):
-                for _ in range(3):
-                    g_res = ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
-                    g_logits = head(g_res["pooled"])
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(graph):
-                g_res = ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
-                g_logits = head(g_res["pooled"])
-        except Exception as e:  # capture is an optimisation, never a requirement
-            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize(dev)
+    n_lanes = max(1, args.lanes)
+    lanes = LaneExecutor(params, local_rank, n_lanes, head=None, first_extractor=ex)
+    kw = dict(pooled=True, frames=want_frames, tuning=(args.preset == "reference_149"))
 
-    # Consecutive batches are independent, so they alternate between `--lanes` HIP streams (one extractor handle, i.e.
-    # one log-mel workspace, per lane): the STFT kernel of one batch overlaps the MFCC kernel, the head and (N > 1) the
-    # logits gather of the previous one.  Both kernels are latency bound with idle pipes, so the
-    # overlap is real throughput: measured 257 -> 225 us per step with two lanes.  Everything is joined back into the
-    # main stream before the closing fence, so the timed region still contains all of its work.
-    n_lanes = 1 if graph is not None else max(1, args.lanes)
-    lanes = LaneExecutor(params, local_rank, n_lanes, head=head, first_extractor=ex)
-
-    def gather(res):
-        res["all_logits"] = gather_rows(res["logits"], BATCH * world, rank, world)
+    def after(res):
+        res["logits"] = run_head(res)
+        res["all_logits"] = gather_rows(res["logits"], total, rank, world)
 
     def step():
-        if graph is not None:
-            graph.replay()
-            return gather_rows(g_logits, BATCH * world, rank, world), g_res
-        res = lanes.submit(pcm, offsets, N_SAMPLES, after=gather, pooled=True, frames=True)
-        return res["all_logits"], res
+        if args.config == 4:   # one big resident shard: 2048-clip chunks alternate between the lanes, then head + gather
+            res = lanes.extract_large(pcm, offsets, N_SAMPLES, chunk_clips=2048, pooled=True, frames=False)
+            after(res)
+            return res
+        return lanes.submit(pcm, offsets, N_SAMPLES, after=after, **kw)
 
+    per_kernel = []
     with torch.no_grad():
         lanes.fork()
-        # untimed: first-use work of every lane (workspace allocation, kernel attributes) and the GPU's clock ramp are
-        # kept out of short timed regions by a fixed number of extra launches ahead of the W requested warm-up steps
-        for _ in range(args.warmup + (0 if args.no_preheat else 60)):
+        for _ in range(args.warmup):
             step()
         lanes.join()
         fence()
         # one event pair around the whole timed loop: hundreds of live timing events (one pair per step) exhaust the
-        # runtime's signal pool and serialise the launches (measured: 0.29 ms/step at 50 steps, 0.43-0.52 at 200)
+        # runtime's signal pool and serialise the launches
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         lanes.fork()
         for _ in range(args.steps):
-            all_logits, res = step()
+            res = step()
         lanes.join()
         ev1.record()
         fence()
         dt = time.perf_counter() - t0
+        all_logits = res["all_logits"]
         # for transparency: the same step strictly serially on one stream (outside the timed region, not `value`)
         serial_ms = None
-        if graph is None and n_lanes > 1:
+        if n_lanes > 1 and args.config == 2:
             sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_serial = min(50, args.steps)
             sv0.record()
             for _ in range(n_serial):
-                r1 = ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
-                gather_rows(head(r1["pooled"]), BATCH * world, rank, world)
+                r1 = ex.extract_batch_device(pcm, offsets, N_SAMPLES, **kw)
+                gather_rows(run_head(r1), total, rank, world)
             sv1.record()
             torch.cuda.synchronize(dev)
             serial_ms = sv0.elapsed_time(sv1) / n_serial
-        # per-kernel durations: a few extra launches outside the timed region, events inside the library
+        # per-kernel durations: a few extra launches outside the timed region, HIP events inside the library (on the
+        # launch stream) around each kernel
+        k_pcm, k_off, k_n = (pcm, offsets, n_local) if args.config == 2 else (bank_dev.reshape(-1), offsets[:BATCH + 1], BATCH)
         ex.kernel_timing(True)
-        for _ in range(min(10, args.steps)):
-            ex.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, frames=True)
+        for _ in range(10):
+            ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)
             per_kernel.append(ex.kernel_timing(True))
         ex.kernel_timing(False)
-    assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (BATCH * world, 3)
-    assert bool(torch.isfinite(res["frames"]).all())
+        cnn_ms = None
+        if cnn is not None:
+            fr = ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)["frames"]
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cnn(fr)
+            c0.record()
+            for _ in range(10):
+                cnn(fr)
+            c1.record()
+            torch.cuda.synchronize(dev)
+            cnn_ms = c0.elapsed_time(c1) / 10
+        # measured device-to-device copy rate (report the fraction of the measured copy bandwidth too)
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        b1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 5 * 2 * src.numel() * 4 / (b0.elapsed_time(b1) * 1e-3) / 1e9
+        del src, dst
+        # configs[3]: the gathered arg-max must equal the single-GPU result of the same clips (clip j = bank clip j mod 1024)
+        argmax_ok = None
+        if args.config == 4:
+            ref = run_head(ex.extract_batch_device(bank_dev.reshape(-1), offsets[:BATCH + 1], N_SAMPLES, pooled=True)).argmax(dim=1)
+            got = all_logits.argmax(dim=1)
+            argmax_ok = bool(torch.equal(got, ref[torch.arange(total, device=dev) % BATCH]))
+            assert argmax_ok, "gathered arg-max differs from the single-GPU result"
+        # PCIe-inclusive rate (N = 1): host int16 -> H2D overlapped with the kernels -> pooled rows back on the host
+        host_rate = None
+        if world == 1 and not args.no_host_rate and args.config == 2 and cnn is None:
+            from rsd_amd.ingest import StreamingExtractor
+            n_host = 8192
+            flat = np.tile(bank.reshape(-1), n_host // BATCH)
+            hoff = np.arange(n_host + 1, dtype=np.int64) * N_SAMPLES
+            se = StreamingExtractor(ex, chunk_clips=2048)
+            se.run(flat[: 2048 * N_SAMPLES], hoff[:2049])
+            th = time.perf_counter()
+            out = se.run(flat, hoff)
+            th = time.perf_counter() - th
+            assert int(np.abs(out["status"]).sum()) == 0
+            host_rate = {"clips_per_s": round(n_host / th, 1), "pcm_gb_per_s": round(n_host * N_SAMPLES * 2 / th / 1e9, 2),
+                         "h2d_gb_per_s": round(se.h2d_gbs, 2) if getattr(se, "h2d_gbs", None) else None,
+                         "clips": n_host, "path": se.describe() if hasattr(se, "describe") else "pinned staging, double-buffered H2D"}
+    assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3)
+    assert bool(torch.isfinite(all_logits).all())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,47 +344,81 @@ def main():
     kms = ev0.elapsed_time(ev1) / max(1, args.steps)  # GPU time per step on the launch stream
 
     if rank == 0:
-        clips_per_s = BATCH * world * args.steps / dt
-        algo_bytes = BATCH * (2 * N_SAMPLES + 4 * (ex.frame_rows * T + ex.pooled_dim))  # PCM read once + outputs written once
-        k_stft = float(np.median([p["stft_mel"] for p in per_kernel]))
-        k_mfcc = float(np.median([p["mfcc"] for p in per_kernel]))
-        k_path = k_stft + k_mfcc  # the feature launch: both kernels back to back on one stream
+        clips_per_s = total * args.steps / dt if args.config == 4 else BATCH * world * args.steps / dt
+        out_elems = ex.pooled_dim + (ex.frame_rows * T if want_frames else 0)
+        bytes_per_clip = 2 * N_SAMPLES + 4 * out_elems        # PCM read once + outputs written once
+        algo_bytes = BATCH * bytes_per_clip                   # per 1024-clip launch (the unit the kernels are timed on)
+        med = lambda k: float(np.median([p[k] for p in per_kernel]))  # noqa: E731
+        k_stft, k_mfcc, k_chroma = med("stft_mel"), med("mfcc"), med("chroma")
+        k_path = k_stft + k_mfcc + (k_chroma if params.chroma else 0.0)
         achieved = algo_bytes / (k_path * 1e-3) / 1e9
-        logmel_bytes = BATCH * T * ((params.n_mels + 15) // 16 * 16) * 4  # the one HBM intermediate (written by one kernel, read by the other)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # hardware counters are collected in separate rocprofv3 --pmc passes (tools/pmc.sh) and committed with the id
+        # of the kernel sources they were measured on; a stale file is not quoted
+        counters = None
+        cpath = os.path.join(ROOT, "profiles", "r02_counters.json")
+        if os.path.exists(cpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                c = json.load(open(cpath)).get(args.preset if cnn is None else "cnn")
+                if c and c.get("kernel_source_id") == kernel_source_id():
+                    counters = c
             except Exception:
-                traffic = None
+                counters = None
+        workload = {
+            (2, "bench_512", "mlp"): "BASELINE.json configs[1]: 1024 clips x 48000 int16 samples per GPU resident in HBM, 512-pt STFT hop "
+                                     "160, 64 Slaney mels, top_db 80, 40 MFCC + delta + delta2; outputs frame-level [1024,120,301] fp32 + "
+                                     "pooled [1024,240] fp32, then MLP head -> logits [1024,3] and (N>1) RCCL all-gather of the logits",
+            (2, "bench_512", "cnn"): "BASELINE.json configs[2]: configs[1] + the 2-layer CNN head (conv 1->32, pool, conv 32->64, global "
+                                     "average, linear 64->3; random weights) on the frame-level rows [1024,120,301], HIP kernels",
+            (4, "bench_512", "mlp"): "BASELINE.json configs[3]: 100000 clips (clip j = bank clip j mod 1024) x 48000 int16 samples, contiguous "
+                                     "shards resident in HBM, BENCH_512 pooled rows [n_local,240] -> MLP head -> one all-gather of [n_local,3] "
+                                     "logits; gathered arg-max checked against the single-GPU result",
+            (2, "reference_149", "mlp"): "the reference's own parameterisation (pipeline1.py:216-228): 1024 clips x 48000 int16 samples per "
+                                         "GPU resident in HBM, 2048-pt STFT hop 512, 128 Slaney mels, 20 MFCC + delta + delta2 + chroma_stft "
+                                         "(tuning estimate), parity mode (float64 FFT), pooled [1024,144] fp32 -> MLP(149->128->64->3)",
+        }[(args.config, args.preset, args.head)]
         out = {
-            "metric": "clips/sec (3 s@16 kHz, 40-MFCC) end-to-end",
-            "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 1024 clips x 48000 int16 samples per GPU resident in HBM, "
-                                   "512-pt STFT hop 160, 64 Slaney mels, top_db 80, 40 MFCC + delta + delta2; outputs "
-                                   "frame-level [1024,120,301] fp32 + pooled [1024,240] fp32, then MLP head -> logits "
-                                   "[1024,3] and (N>1) RCCL all-gather of the logits",
-                       "clips_per_gpu": BATCH, "samples_per_clip": N_SAMPLES, "n_fft": 512, "hop": 160,
-                       "n_mels": 64, "n_mfcc": 40, "frames_per_clip": T, "untimed_preheat_launches": 0 if args.no_preheat else 60, "one_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4), "parallelism": f"clip-sharded x{world}", "launch": "hipGraph replay" if graph is not None else ("eager, batches alternate between %d streams" % n_lanes if n_lanes > 1 else "eager, one stream")},
-            # dominant kernel = the STFT+mel kernel; its own algorithmic bytes are the PCM it reads plus the log-mel it
-            # writes.  `path` prices the whole feature launch (both kernels) with the SURVEY 8d bytes (no intermediates).
-            "roofline": {"bound": "hbm", "kernel": "dysf_stft_mel_kernel<256, i16, 256>",
-                         "achieved": round((BATCH * 2 * N_SAMPLES + logmel_bytes) / (k_stft * 1e-3) / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round((BATCH * 2 * N_SAMPLES + logmel_bytes) / (k_stft * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(k_stft, 4),
-                         "algorithmic_bytes_per_launch": BATCH * 2 * N_SAMPLES + logmel_bytes,
-                         "second_kernel": {"kernel": "dysf_mfcc_kernel<512>", "kernel_ms": round(k_mfcc, 4),
-                                           "algorithmic_bytes_per_launch": logmel_bytes + algo_bytes - BATCH * 2 * N_SAMPLES,
-                                           "achieved": round((logmel_bytes + algo_bytes - BATCH * 2 * N_SAMPLES) / (k_mfcc * 1e-3) / 1e9, 1)},
-                         "path": {"kernels": "stft_mel + mfcc", "ms": round(k_path, 4), "step_gpu_ms": round(kms, 4),
-                                  "algorithmic_bytes_per_launch": algo_bytes, "achieved": round(achieved, 1),
-                                  "frac": round(achieved / HBM_PEAK_GBS, 4),
-                                  "clips_per_s": round(BATCH / (k_path * 1e-3), 1)}},
+            "metric": "clips/sec (3 s@16 kHz, 40-MFCC) end-to-end", "value": round(clips_per_s, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None,
+            "dtype": "f64" if params.parity else "f32", "data": "synthetic",
+            "config": {"workload": workload, "input": "PCM resident in HBM before the timed region (PCIe-inclusive rate: config.from_host)",
+                       "clips_per_gpu": n_local, "total_clips": total, "samples_per_clip": N_SAMPLES, "n_fft": params.n_fft,
+                       "hop": params.hop, "n_mels": params.n_mels, "n_mfcc": params.n_mfcc, "frames_per_clip": T,
+                       "head": args.head, "gathered_argmax_equals_single_gpu": argmax_ok,
+                       "one_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
+                       "step_gpu_ms": round(kms, 4), "parallelism": f"clip-sharded x{world}",
+                       "launch": ("eager, batches alternate between %d streams" % n_lanes) if n_lanes > 1 else "eager, one stream",
+                       "from_host": host_rate,
+                       "pcie_ceiling_clips_per_s": round(63e9 / (2 * N_SAMPLES), 1)},
+            # HBM is the roofline SURVEY 8d prices this path against: bytes = PCM read once + outputs written once (no
+            # intermediates), time = the feature launch's kernels back to back on one stream.  The kernels are NOT bandwidth
+            # bound: `limited_by` says what the counters show.
+            "roofline": {"bound": "hbm", "kernel": "feature launch: dysf_stft_mel_kernel + dysf_mfcc_kernel" + (" + dysf_chroma_kernel" if params.chroma else ""),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (counters or {}).get("hbm_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_clip": bytes_per_clip, "clips_per_launch": BATCH,
+                         "kernel_ms": round(k_path, 4), "measured_copy_gbs": round(copy_gbs, 1),
+                         "frac_of_measured_copy_bw": round(achieved / copy_gbs, 4),
+                         "limited_by": (counters or {}).get("limited_by", "instruction issue / dependent latency, not HBM (see DESIGN.md section 5)"),
+                         "valu_busy": (counters or {}).get("valu_busy"), "mfma_busy": (counters or {}).get("mfma_busy"),
+                         "counters_from": (counters or {}).get("source"),
+                         "kernels": {"dysf_stft_mel_kernel": {"ms": round(k_stft, 4), "algorithmic_bytes": BATCH * 2 * N_SAMPLES,
+                                                              "achieved_gbs": round(BATCH * 2 * N_SAMPLES / (k_stft * 1e-3) / 1e9, 1)},
+                                     "dysf_mfcc_kernel": {"ms": round(k_mfcc, 4), "algorithmic_bytes": BATCH * 4 * out_elems,
+                                                          "achieved_gbs": round(BATCH * 4 * out_elems / (k_mfcc * 1e-3) / 1e9, 1)}},
+                         "clips_per_s_kernels_only": round(BATCH / (k_path * 1e-3), 1)},
         }
+        if params.chroma:
+            out["roofline"]["kernels"]["dysf_chroma_kernel"] = {"ms": round(k_chroma, 4)}
+        if cnn is not None:   # configs[2]: the dominant kernel is the CNN's conv2 (implicit GEMM on MFMA)
+            flops = BATCH * (2 * 32 * 9 * 120 * 301 + 2 * 64 * 32 * 9 * 60 * 150)
+            tf = flops / (cnn_ms * 1e-3) / 1e12
+            prec = getattr(cnn, "precision", "f16")
+            peak = MFMA_F16_PEAK_TF if prec == "f16" else MFMA_F32_PEAK_TF
+            out["roofline"] = {"bound": "mfma", "kernel": "dysf_cnn_* (conv1 + pool + conv2 + average + linear)", "achieved": round(tf, 2),
+                               "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                               "algorithmic_flops_per_launch": flops, "kernel_ms": round(cnn_ms, 4), "conv2_precision": prec,
+                               "feature_kernels_ms": round(k_path, 4)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -623,7 +623,9 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
       const int fl = wave * FPW + q;  // frame within tile
       if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, a);
       else wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
+      STAMP(1);  // prefetch issue + FFT
       if (a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
+      STAMP(7);  // piptrack
       if (sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
 #pragma unroll
         for (int qq = 0; qq < FPW; ++qq) {
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
         }
       }
     }
-    STAMP(1);  // prefetch issue + FFT
+    STAMP(14);  // spectrogram rows to the workspace
     __syncthreads();  // S tile complete; every wave is done reading the PCM tile
     STAMP(2);  // barrier
     if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, pbase, n32, r0, ngroups);

@@ -635,20 +635,34 @@ def test_fused_cnn_head_vs_torch_module(ex512):
     fused.close()
 
 
-def test_bench_two_ranks_rehearsal():
-    """The N > 1 path of bench.py (one process per rank, lanes, the logits all-gather on each lane's stream, max-over-ranks
-    timing) rehearsed with two ranks that share this box's GPU and a gloo gather (--share-gpu; never a measurement)."""
+def _run_bench(*flags, timeout=400):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
-           "--share-gpu", "--no-cpu-baseline", "--no-preheat", "--bank-workers", "2"]
-    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], cwd=root, capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` exactly as a shell would invoke it: the script starts its own two rank processes (lanes,
+    the logits all-gather on each lane's stream, max-over-ranks timing).  Rehearsed with both ranks on this box's GPU and a
+    gloo gather (--share-gpu; never a measurement)."""
+    d = _run_bench("--gpus", "2", "--steps", "6", "--warmup", "2", "--share-gpu", "--no-cpu-baseline", "--bank-workers", "2")
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    r = d["roofline"]   # frac follows from the SURVEY 8d bytes and the measured kernel time alone
+    assert r["bytes_per_clip"] == 2 * 48000 + 4 * (120 * 301 + 240)
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 2e-4
+
+
+def test_bench_config4_two_ranks_rehearsal():
+    """BASELINE configs[3] through the same self-launch path: 100 000 clips in two 50 000-clip shards (extract_large over the
+    lanes), one all-gather of [50 000, 3] logits, gathered arg-max equal to the single-GPU result."""
+    d = _run_bench("--gpus", "2", "--config", "4", "--steps", "2", "--warmup", "1", "--share-gpu", "--no-cpu-baseline",
+                   "--bank-workers", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_clips"] == 100000
+    assert d["config"]["clips_per_gpu"] == 50000 and d["config"]["gathered_argmax_equals_single_gpu"] is True
 
 
 def test_lane_executor_large_batch_equals_single_call(ex512):

@@ -204,3 +204,16 @@ def test_sharding_properties_hypothesis():
 
     check_range()
     check_samples()
+
+
+def test_bench_self_launch_propagates_a_failed_rank(tmp_path):
+    """`python bench.py --gpus 2` starts its own rank processes before anything touches the GPU and returns their exit
+    code: on this GPU-less box both ranks die in torch.cuda.set_device and the parent must report it (no hang)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--bank-workers", "1"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" not in out.stderr
