@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DYSF_ABI_VERSION 1
+#define DYSF_ABI_VERSION 2
 
 /* per-clip status (int32) */
 #define DYSF_OK            0
@@ -228,14 +228,19 @@ int32_t dysf_resample_batch_dev(DysfResampler* r, const void* d_pcm, int32_t pcm
  * conv1 runs in float32; conv2 on the float16 MFMA with float32 accumulation (the precision configs[4] asks for).
  *   d_logits [n, n_classes] float32
  */
+#define DYSF_CNN_F16 0 /* conv2 on v_mfma_f32_16x16x32_f16: float16 operands, float32 accumulation (BASELINE configs[4]) */
+#define DYSF_CNN_F32 1 /* conv2 on v_mfma_f32_16x16x4_f32: the float32 module of configs[2], exact fmaf chains          */
 typedef struct DysfCnn DysfCnn;
 const char* dysf_cnn_last_error(void);
-int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w, const float* conv1_b,
+int32_t dysf_cnn_create(int32_t device, int32_t n_classes, int32_t precision, const float* conv1_w, const float* conv1_b,
                         const float* conv2_w, const float* conv2_b, const float* fc_w, const float* fc_b,
                         DysfCnn** out);
 void    dysf_cnn_destroy(DysfCnn* m);
+/* cols = the widest clip's valid columns; d_cols = [n] int32 valid columns of every clip on the device, or NULL when all
+ * clips have `cols` (ragged batches, BASELINE configs[4]: each clip is convolved, pooled and averaged over its own width).
+ * A handle owns one partial-sum workspace: use one handle per stream (work queued on one stream is ordered).            */
 int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols,
-                             int64_t row_stride, float* d_logits, void* stream);
+                             const int32_t* d_cols, int64_t row_stride, float* d_logits, void* stream);
 
 #ifdef __cplusplus
 }

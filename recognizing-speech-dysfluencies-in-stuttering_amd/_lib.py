@@ -9,6 +9,8 @@ LIB_PATH = os.environ.get("DYSF_LIB") or os.path.join(_HERE, "libdysf_hip.so")  
 DYSF_OK, DYSF_TOO_SHORT, DYSF_NONFINITE, DYSF_EMPTY = 0, 1, 2, 3
 STATUS_NAMES = {0: "OK", 1: "TOO_SHORT", 2: "NONFINITE", 3: "EMPTY", 4: "TOO_LONG"}
 PCM_I16, PCM_F32 = 0, 1
+CNN_F16, CNN_F32 = 0, 1
+ABI_VERSION = 2   # include/dysf_hip.h DYSF_ABI_VERSION
 PRESET_REFERENCE_149, PRESET_BENCH_512 = 0, 1
 
 #: every symbol include/dysf_hip.h declares (tests check the .so exports all of them)
@@ -102,13 +104,13 @@ def lib():
     L.dysf_resampler_out_len.restype = i64
     L.dysf_resample_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i64, vp]
     L.dysf_cnn_last_error.restype = ctypes.c_char_p
-    L.dysf_cnn_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dysf_cnn_create.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
     L.dysf_cnn_destroy.argtypes = [vp]
     L.dysf_cnn_destroy.restype = None
-    L.dysf_cnn_forward_dev.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp]
+    L.dysf_cnn_forward_dev.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
-    if L.dysf_abi_version() != 1:
+    if L.dysf_abi_version() != ABI_VERSION:
         raise DysfError("libdysf_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -320,49 +320,68 @@ class CNNHead(nn.Module):
 
 class FusedCNNHead:
     """``CNNHead`` evaluated by hand-written HIP kernels behind the C ABI (``dysf_cnn_*``): conv1 + ReLU + max-pool in
-    float32, conv2 as an implicit GEMM on the float16 MFMA with float32 accumulation, pooled sums, Linear.  Takes the
-    frame-level tensor [n, rows, T] exactly as ``extract_batch_device(frames=True)`` returns it (no copy, any row
-    pitch).  Built from a ``CNNHead`` (or any module with conv1 / conv2 / fc of those shapes)."""
+    float32, conv2 as an implicit GEMM on the MFMA, pooled sums, Linear.  ``precision="f16"`` (default; BASELINE
+    configs[4]) runs conv2 on the float16 MFMA with float32 accumulation; ``precision="f32"`` runs it on the float32 MFMA
+    (configs[2]: arg-max equal to the float32 CPU module).  Takes the frame-level tensor [n, rows, T] exactly as
+    ``extract_batch_device(frames=True)`` returns it (no copy, any row pitch); ``cols`` may be a per-clip int32 tensor of
+    valid widths (ragged batches).  One C handle (= one partial-sum workspace) per HIP stream the head is used on."""
 
-    def __init__(self, module: "CNNHead", device: int = 0):
-        import ctypes
+    def __init__(self, module: "CNNHead", device: int = 0, precision: str = "f16"):
         from . import _lib
         self._lib = _lib
         self.device = device
+        if precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.precision = precision
         f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), np.float32)  # noqa: E731
-        arrs = [f(module.conv1.weight), f(module.conv1.bias), f(module.conv2.weight), f(module.conv2.bias),
-                f(module.fc.weight), f(module.fc.bias)]
-        if arrs[0].shape != (32, 1, 3, 3) or arrs[2].shape != (64, 32, 3, 3) or arrs[4].shape[1] != 64:
+        self._arrs = [f(module.conv1.weight), f(module.conv1.bias), f(module.conv2.weight), f(module.conv2.bias),
+                      f(module.fc.weight), f(module.fc.bias)]
+        a = self._arrs
+        if a[0].shape != (32, 1, 3, 3) or a[2].shape != (64, 32, 3, 3) or a[4].shape[1] != 64:
             raise ValueError("FusedCNNHead implements Conv(1->32,3x3) / Conv(32->64,3x3) / Linear(64->k) only")
-        self.n_classes = int(arrs[4].shape[0])
-        self._h = ctypes.c_void_p()
-        L = _lib.lib()
-        rc = L.dysf_cnn_create(device, self.n_classes, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
-                               ctypes.byref(self._h))
-        if rc != 0:
-            raise _lib.DysfError(f"dysf_cnn_create failed ({rc}): {L.dysf_cnn_last_error().decode()}")
+        self.n_classes = int(a[4].shape[0])
+        self._handles = {}
+        self._handle(0)
+
+    def _handle(self, stream_id: int):
+        import ctypes
+        h = self._handles.get(stream_id)
+        if h is None:
+            h = ctypes.c_void_p()
+            L = self._lib.lib()
+            rc = L.dysf_cnn_create(self.device, self.n_classes, self._lib.CNN_F32 if self.precision == "f32" else self._lib.CNN_F16,
+                                   *[a.ctypes.data_as(ctypes.c_void_p) for a in self._arrs], ctypes.byref(h))
+            if rc != 0:
+                raise self._lib.DysfError(f"dysf_cnn_create failed ({rc}): {L.dysf_cnn_last_error().decode()}")
+            self._handles[stream_id] = h
+        return h
 
     def __call__(self, frames: torch.Tensor, cols=None) -> torch.Tensor:
-        """frames: [n, rows, pitch] float32 CUDA tensor (last dimension contiguous); ``cols`` valid columns per row
-        (default: all)."""
+        """frames: [n, rows, pitch] float32 CUDA tensor (last dimension contiguous); ``cols``: valid columns -- an int
+        for the whole batch (default: all), or an int32 CUDA tensor [n] of per-clip widths."""
         import ctypes
         assert frames.is_cuda and frames.dtype == torch.float32 and frames.dim() == 3 and frames.stride(2) == 1
         assert frames.stride(0) == frames.shape[1] * frames.stride(1)
         n, rows, pitch = frames.shape[0], frames.shape[1], frames.stride(1)
+        d_cols = None
+        if torch.is_tensor(cols):
+            assert cols.is_cuda and cols.dtype == torch.int32 and cols.is_contiguous() and cols.numel() == n
+            d_cols, cols = ctypes.c_void_p(cols.data_ptr()), int(frames.shape[2])
         cols = int(frames.shape[2] if cols is None else cols)
         out = torch.empty((n, self.n_classes), dtype=torch.float32, device=frames.device)
         L = self._lib.lib()
-        rc = L.dysf_cnn_forward_dev(self._h, ctypes.c_void_p(frames.data_ptr()), n, rows, cols, pitch,
-                                    ctypes.c_void_p(out.data_ptr()),
-                                    ctypes.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream))
+        stream = torch.cuda.current_stream(frames.device)
+        rc = L.dysf_cnn_forward_dev(self._handle(stream.cuda_stream), ctypes.c_void_p(frames.data_ptr()), n, rows, cols, d_cols,
+                                    pitch, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
         if rc != 0:
             raise self._lib.DysfError(f"dysf_cnn_forward_dev failed ({rc}): {L.dysf_cnn_last_error().decode()}")
         return out
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.lib().dysf_cnn_destroy(self._h)
-            self._h.value = None
+        for h in getattr(self, "_handles", {}).values():
+            if h.value:
+                self._lib.lib().dysf_cnn_destroy(h)
+        self._handles = {}
 
     def __del__(self):
         try:

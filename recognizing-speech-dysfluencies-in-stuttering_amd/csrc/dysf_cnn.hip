@@ -13,10 +13,15 @@
 //                             accumulation, per-channel sums reduced in registers into the workgroup's slot of sums[clip][tile][64].
 //   mean + Linear             one thread per (clip, class).
 // conv2 is 92 % of the arithmetic (332 of 353 MFLOP per clip); float16 operands with float32 accumulation is the
-// precision BASELINE configs[4] asks of the CNN ("fp16 MFMA CNN").
+// precision BASELINE configs[4] asks of the CNN ("fp16 MFMA CNN").  A handle created with DYSF_CNN_F32 runs conv2 on
+// v_mfma_f32_16x16x4_f32 instead (float32 activations in LDS, an exact fmaf chain per output): the float32 result
+// configs[2] is checked against (arg-max equal to the float32 CPU module on every clip), at 1/16 of the MFMA rate.
+// Clips of different lengths share one launch: cols[clip] valid columns per clip (BASELINE configs[4]), everything
+// past them -- conv padding, pooling, the global average -- behaves as if the clip had been run alone.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -39,12 +44,16 @@ constexpr int kPixPitch = 40;        // float16 per pixel in LDS (32 channels + 
                                      // neighbouring pixels 20 banks apart)
 
 struct CnnDev {
-  int H, W, stride;                  // input rows (3*n_mfcc), valid columns (frames), row pitch in floats
-  int PH, PW;                        // pooled size: H/2, W/2
+  int H, W, stride;                  // input rows (3*n_mfcc), valid columns (frames; the batch maximum), row pitch in floats
+  int PH, PW;                        // pooled size: H/2, W/2 (batch maximum)
+  const int* cols;                   // [n] valid columns of every clip (null: all W)
   int AW;                            // act1 row pitch in pixels (PW + 2, rounded up to a multiple of 16 + 2)
+  int CW, TW, ctiles;                // conv2 workgroup tile: CW pooled columns (a multiple of 16), LDS row pitch TW = CW + 2
+                                     // pixels, column tiles per row tile (wide maps are cut so that the tile fits in LDS)
   int n_classes;
   const float* w1;                   // conv1: [32 channels][9 taps + bias]
   const _Float16* w2p;               // [4 oc tiles][9 taps][64 lanes][8] A operands of conv2
+  const float* w2p32;                // float32 handles: [4 oc tiles][9 taps][2 groups of 16 ic][64 lanes][4 steps]
   const float* b2;                   // [64]
   const float* wfc; const float* bfc;  // [n_classes][64], [n_classes]
   _Float16* act1;                    // [clip][PH + 2][AW][32]
@@ -54,7 +63,8 @@ struct CnnDev {
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv1 + ReLU + 2x2 max-pool of one pooled pixel (py, px), all 32 channels, written as float16 to dst[0..31]
-__device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int py, int px, _Float16* dst) {
+template <typename OT>
+__device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int W, int py, int px, OT* dst) {
   float p[4][4];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2, zero outside the [H x W] image
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -62,7 +72,7 @@ __device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* i
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int x = 2 * px - 1 + c;
-      p[r][c] = (y >= 0 && y < m.H && x >= 0 && x < m.W) ? in[(size_t)y * m.stride + x] : 0.f;
+      p[r][c] = (y >= 0 && y < m.H && x >= 0 && x < W) ? in[(size_t)y * m.stride + x] : 0.f;
     }
   }
   // the weights are wave-uniform: scalar operands of the FMAs
@@ -81,7 +91,7 @@ __device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* i
           for (int kx = 0; kx < 3; ++kx) sacc = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], sacc);
         best = fmaxf(best, sacc);
       }
-    dst[c] = (_Float16)fmaxf(best, 0.f);  // max-pool and ReLU commute
+    dst[c] = (OT)fmaxf(best, 0.f);  // max-pool and ReLU commute
   }
 }
 
@@ -90,8 +100,14 @@ __global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const flo
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= m.PH * m.PW) return;
   const int py = pix / m.PW, px = pix % m.PW;
-  conv1_pool_pixel(m, frames + (size_t)clip * m.H * m.stride, py, px,
-                   m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1);
+  const int W = m.cols ? min(max(m.cols[clip], 0), m.W) : m.W;
+  _Float16* dst = m.act1 + (((size_t)clip * (m.PH + 2) + (py + 1)) * m.AW + (px + 1)) * kC1;
+  if (px < W / 2) {
+    conv1_pool_pixel(m, frames + (size_t)clip * m.H * m.stride, W, py, px, dst);
+  } else {  // past this clip's pooled width: conv2's zero padding
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(int4*)(dst + 8 * q) = make_int4(0, 0, 0, 0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -99,24 +115,28 @@ template <bool FUSED>
 __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const float* frames, int n) {
   extern __shared__ __align__(16) _Float16 tile[];  // [kRowTile + 2][AW][kPixPitch]
   const int clip = blockIdx.y;
-  const int y0 = blockIdx.x * kRowTile;              // first output row of this workgroup
+  const int y0 = (blockIdx.x / m.ctiles) * kRowTile;  // first output row of this workgroup
+  const int cx0 = (blockIdx.x % m.ctiles) * m.CW;     // first output column
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3, half = wave8 >> 2;   // output-channel tile, and which half of the pixel-tile pairs
   const int rows = min(kRowTile, m.PH - y0);
+  const int W = m.cols ? min(max(m.cols[clip], 0), m.W) : m.W;  // this clip's valid columns and pooled width
+  const int PW = W / 2;
+  const int nx = min(PW - cx0, m.CW);                 // output columns of this workgroup (<= 0: nothing to do)
   // rows y0 .. y0 + rows + 1 of the bordered activation map (row r of the map is pooled row r - 1, column c pooled
   // column c - 1; the border and the columns past PW are zero)
   if (FUSED) {
     // conv1 + pool computed straight into the tile: no activation round trip through HBM (the halo rows are computed
     // by both neighbours: 1.5x the conv1 arithmetic, which overlaps other workgroups' MFMA phase)
     const float* in = frames + (size_t)clip * m.H * m.stride;
-    const int npix = (rows + 2) * m.AW;
+    const int npix = (rows + 2) * m.TW;
     for (int i = tid; i < npix; i += 512) {
-      const int j = i / m.AW, c = i % m.AW;
-      const int py = y0 + j - 1, px = c - 1;
+      const int j = i / m.TW, c = i % m.TW;
+      const int py = y0 + j - 1, px = cx0 + c - 1;
       _Float16* dst = tile + (size_t)i * kPixPitch;
-      if (py >= 0 && py < m.PH && px >= 0 && px < m.PW) {
-        conv1_pool_pixel(m, in, py, px, dst);
+      if (py >= 0 && py < m.PH && px >= 0 && px < PW) {
+        conv1_pool_pixel(m, in, W, py, px, dst);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(int4*)(dst + 8 * q) = make_int4(0, 0, 0, 0);
@@ -124,10 +144,11 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
     }
   } else {
     const _Float16* src = m.act1 + ((size_t)clip * (m.PH + 2) + y0) * m.AW * kC1;
-    const int nchunks = (rows + 2) * m.AW * 4;  // 16-byte chunks: 4 per pixel
+    const int nchunks = (rows + 2) * m.TW * 4;  // 16-byte chunks: 4 per pixel
     for (int i = tid; i < nchunks; i += 512) {
       const int pixel = i >> 2, part = i & 3;
-      const int4 v = *(const int4*)(src + (size_t)pixel * kC1 + part * 8);
+      const int j = pixel / m.TW, c = cx0 + pixel % m.TW;   // row and column of the bordered map
+      const int4 v = (c < m.AW) ? *(const int4*)(src + ((size_t)j * m.AW + c) * kC1 + part * 8) : make_int4(0, 0, 0, 0);
       *(int4*)(tile + (size_t)pixel * kPixPitch + part * 8) = v;
     }
   }
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
   float bias[4], rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = m.b2[16 * wave + 4 * kg + r];
-  const int xtiles = (m.PW + 15) / 16;
+  const int xtiles = (max(nx, 0) + 15) / 16;   // this clip's pixel tiles: the columns past its pooled width cost nothing
   const int pairs = (xtiles + 1) / 2;
   for (int item = half; item < rows * pairs; item += 2) {  // the two waves of an output-channel tile alternate
     const int ry = item / pairs;
@@ -153,7 +174,7 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
       for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t % 3;
         // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx; lane kg supplies channels 8kg .. 8kg+7
-        const _Float16* bp = tile + ((size_t)(ry + ky) * m.AW + (x + kx)) * kPixPitch + 8 * kg;
+        const _Float16* bp = tile + ((size_t)(ry + ky) * m.TW + (x + kx)) * kPixPitch + 8 * kg;
         const h8 b0 = *(const h8*)bp;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b0, acc0, 0, 0, 0);
         if (two) {
@@ -161,17 +182,107 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b1, acc1, 0, 0, 0);
         }
       }
-      if (x < m.PW) {
+      if (x < nx) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc0[r] + bias[r], 0.f);
       }
-      if (two && x + 16 < m.PW) {
+      if (two && x + 16 < nx) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc1[r] + bias[r], 0.f);
       }
     }
   }
   // sum over the 16 pixel columns (lanes with equal lane >> 4); the workgroup's partial sums go to its own slot
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = rs[r];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (ncol == 0) m.sums[(((size_t)clip * m.n_tiles + blockIdx.x) * 2 + half) * kC2 + 16 * wave + 4 * kg + r] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float32 form of conv2 (handles created with DYSF_CNN_F32): conv1 + pool straight into a float32 LDS tile, conv2 on
+// v_mfma_f32_16x16x4_f32.  K = (tap, input channel) is walked per tap in two groups of 16 channels; lane (pixel = l & 15,
+// q = l >> 4) reads channels 16G + 4q .. + 3 of its pixel with one ds_read_b128 and feeds them to four MFMA steps, the
+// weight pack being laid out to match ([oc tile][tap][G][lane][step] -> input channel 16G + 4q + step).  The 72 A operands
+// of the wave's output-channel tile stay in registers.
+constexpr int kPixPitch32 = 36;      // floats per pixel in LDS: 32 channels + 4 of padding (144 bytes, 16-byte aligned)
+
+__global__ __launch_bounds__(512, 2) void dysf_cnn_conv2_f32_kernel(CnnDev m, const float* frames, int n) {
+  extern __shared__ __align__(16) float tile32[];  // [kRowTile + 2][AW][kPixPitch32]
+  const int clip = blockIdx.y;
+  const int y0 = (blockIdx.x / m.ctiles) * kRowTile;
+  const int cx0 = (blockIdx.x % m.ctiles) * m.CW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3, half = wave8 >> 2;
+  const int rows = min(kRowTile, m.PH - y0);
+  const int W = m.cols ? min(max(m.cols[clip], 0), m.W) : m.W;
+  const int PW = W / 2;
+  const int nx = min(PW - cx0, m.CW);
+  {
+    const float* in = frames + (size_t)clip * m.H * m.stride;
+    const int npix = (rows + 2) * m.TW;
+    for (int i = tid; i < npix; i += 512) {
+      const int j = i / m.TW, c = i % m.TW;
+      const int py = y0 + j - 1, px = cx0 + c - 1;
+      float* dst = tile32 + (size_t)i * kPixPitch32;
+      if (py >= 0 && py < m.PH && px >= 0 && px < PW) {
+        conv1_pool_pixel(m, in, W, py, px, dst);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(f4*)(dst + 4 * q) = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  f4 wa[18];  // [tap][G]: four MFMA steps each
+#pragma unroll
+  for (int t = 0; t < 18; ++t) wa[t] = *(const f4*)(m.w2p32 + (((size_t)wave * 18 + t) * 64 + lane) * 4);
+  __syncthreads();
+  const int ncol = lane & 15, kg = lane >> 4;
+  float bias[4], rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = m.b2[16 * wave + 4 * kg + r];
+  const int xtiles = (max(nx, 0) + 15) / 16;
+  const int pairs = (xtiles + 1) / 2;
+  for (int item = half; item < rows * pairs; item += 2) {
+    const int ry = item / pairs;
+    const int xt = 2 * (item % pairs);
+    const int x = 16 * xt + ncol;
+    const bool two = xt + 1 < xtiles;  // wave-uniform
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ky = t / 3, kx = t % 3;
+      const float* bp = tile32 + ((size_t)(ry + ky) * m.TW + (x + kx)) * kPixPitch32 + 4 * kg;
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        const f4 a4 = wa[2 * t + G];
+        const f4 b0 = *(const f4*)(bp + 16 * G);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b0[0], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b0[1], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b0[2], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b0[3], acc0, 0, 0, 0);
+        if (two) {
+          const f4 b1 = *(const f4*)(bp + 16 * kPixPitch32 + 16 * G);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b1[0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b1[1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b1[2], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b1[3], acc1, 0, 0, 0);
+        }
+      }
+    }
+    if (x < nx) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc0[r] + bias[r], 0.f);
+    }
+    if (two && x + 16 < nx) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] += fmaxf(acc1[r] + bias[r], 0.f);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float v = rs[r];
@@ -189,7 +300,9 @@ __global__ __launch_bounds__(256) void dysf_cnn_fc_kernel(CnnDev m, int n, float
   if (clip >= n) return;
   float tot = 0.f;
   for (int t = 0; t < 2 * m.n_tiles; ++t) tot += m.sums[((size_t)clip * 2 * m.n_tiles + t) * kC2 + lane];
-  const float mean = tot * (1.0f / (float)(m.PH * m.PW));
+  const int W = m.cols ? min(max(m.cols[clip], 0), m.W) : m.W;
+  const int npix = m.PH * (W / 2);  // the clip's own pooled size
+  const float mean = npix > 0 ? tot * (1.0f / (float)npix) : 0.f;
   for (int j = 0; j < m.n_classes; ++j) {
     float v = m.wfc[j * kC2 + lane] * mean;
 #pragma unroll
@@ -207,8 +320,9 @@ struct DysfCnn {
   void* act1 = nullptr; size_t act1_clips = 0;
   void* sums = nullptr; size_t sums_clips = 0;
   int act_h = 0, act_w = 0;  // geometry the workspace was laid out for
-  bool attr_set = false;
-  bool fused = true;  // DYSF_CNN_SPLIT=1: conv1 as its own kernel with the activations in HBM
+  size_t lds_granted[3] = {0, 0, 0};  // dynamic-LDS attribute already raised per conv2 kernel
+  int precision = DYSF_CNN_F16;
+  bool fused = true;  // DYSF_CNN_SPLIT=1: conv1 as its own kernel with the activations in HBM (float16 handles only)
 };
 
 static thread_local std::string g_cerr;
@@ -226,16 +340,28 @@ extern "C" {
 
 const char* dysf_cnn_last_error(void) { return g_cerr.c_str(); }
 
-int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w, const float* conv1_b,
+int32_t dysf_cnn_create(int32_t device, int32_t n_classes, int32_t precision, const float* conv1_w, const float* conv1_b,
                         const float* conv2_w, const float* conv2_b, const float* fc_w, const float* fc_b,
                         DysfCnn** out) {
+  if (precision != DYSF_CNN_F16 && precision != DYSF_CNN_F32) { g_cerr = "precision must be DYSF_CNN_F16 or DYSF_CNN_F32"; return DYSF_E_INVALID; }
   if (!out || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !fc_w || !fc_b) { g_cerr = "null argument"; return DYSF_E_INVALID; }
   *out = nullptr;
   if (n_classes < 1 || n_classes > 64) { g_cerr = "n_classes out of range"; return DYSF_E_INVALID; }
   DysfCnn* m = new (std::nothrow) DysfCnn();
   if (!m) { g_cerr = "out of host memory"; return DYSF_E_NOMEM; }
   m->device = device;
+  m->precision = precision;
   if (hipSetDevice(device) != hipSuccess) { delete m; g_cerr = "hipSetDevice failed"; return DYSF_E_HIP; }
+  // float32 conv2 A operands: [oc tile][tap][G][lane][step]: oc = 16*tile + (lane & 15), ic = 16*G + 4*(lane >> 4) + step
+  std::vector<float> w2p32((size_t)4 * 9 * 2 * 64 * 4);
+  for (int tile = 0; tile < 4; ++tile)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int G = 0; G < 2; ++G)
+        for (int l = 0; l < 64; ++l)
+          for (int st = 0; st < 4; ++st) {
+            const int oc = 16 * tile + (l & 15), ic = 16 * G + 4 * (l >> 4) + st;
+            w2p32[((((size_t)tile * 9 + tap) * 2 + G) * 64 + l) * 4 + st] = conv2_w[((size_t)oc * kC1 + ic) * 9 + tap];
+          }
   // conv2 A operands: [oc tile][tap][lane][j]: oc = 16*tile + (lane & 15), ic = 8*(lane >> 4) + j
   std::vector<_Float16> w2p((size_t)4 * 9 * 64 * 8);
   for (int tile = 0; tile < 4; ++tile)
@@ -254,7 +380,8 @@ int32_t dysf_cnn_create(int32_t device, int32_t n_classes, const float* conv1_w,
   std::vector<float> b2(conv2_b, conv2_b + kC2), wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
   m->d.n_classes = n_classes;
   if (const char* e = std::getenv("DYSF_CNN_SPLIT")) m->fused = std::atoi(e) == 0;
-  const bool ok = up(m, &m->d.w1, w1p) && up(m, &m->d.w2p, w2p) && up(m, &m->d.b2, b2) &&
+  if (precision == DYSF_CNN_F32) m->fused = true;
+  const bool ok = up(m, &m->d.w1, w1p) && up(m, &m->d.w2p, w2p) && up(m, &m->d.w2p32, w2p32) && up(m, &m->d.b2, b2) &&
                   up(m, &m->d.wfc, wfc) && up(m, &m->d.bfc, bfc);
   if (!ok) { for (void* p : m->bufs) (void)hipFree(p); delete m; g_cerr = "device upload failed"; return DYSF_E_HIP; }
   *out = m;
@@ -270,8 +397,8 @@ void dysf_cnn_destroy(DysfCnn* m) {
   delete m;
 }
 
-int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols, int64_t row_stride,
-                             float* d_logits, void* stream_) {
+int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols, const int32_t* d_cols,
+                             int64_t row_stride, float* d_logits, void* stream_) {
   if (!m || !d_frames || !d_logits || n < 0) { g_cerr = "bad argument"; return DYSF_E_INVALID; }
   if (rows < 2 || cols < 2 || row_stride < cols || rows > 4096 || cols > 65536) { g_cerr = "bad image shape"; return DYSF_E_INVALID; }
   if (n == 0) return 0;
@@ -279,7 +406,7 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   hipStream_t stream = (hipStream_t)stream_;
   if (hipSetDevice(m->device) != hipSuccess) { g_cerr = "hipSetDevice failed"; return DYSF_E_HIP; }
   CnnDev& d = m->d;
-  d.H = rows; d.W = cols; d.stride = (int)row_stride; d.PH = rows / 2; d.PW = cols / 2;
+  d.H = rows; d.W = cols; d.stride = (int)row_stride; d.PH = rows / 2; d.PW = cols / 2; d.cols = d_cols;
   d.AW = (d.PW + 15) / 16 * 16 + 2;  // the last x tile reads up to column 16*xtiles + 1 of the bordered map
   const size_t act_per_clip = (size_t)(d.PH + 2) * d.AW * kC1 * sizeof(_Float16);
   if (!m->fused && ((size_t)n > m->act1_clips || rows != m->act_h || cols != m->act_w)) {
@@ -289,24 +416,36 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
     if (hipMemsetAsync(m->act1, 0, act_per_clip * n, stream) != hipSuccess) { g_cerr = "hipMemset failed"; return DYSF_E_HIP; }
     m->act1_clips = (size_t)n; m->act_h = rows; m->act_w = cols;
   }
-  d.n_tiles = (d.PH + kRowTile - 1) / kRowTile;
+  const bool f32 = m->precision == DYSF_CNN_F32;
+  // conv2 workgroup tile: kRowTile rows x CW columns (+ the halo) of activations in LDS; wide maps are cut into column tiles
+  const int cw_cap = f32 ? 160 : 320;
+  d.CW = std::min((d.PW + 15) / 16 * 16, cw_cap);
+  if (d.CW < 16) d.CW = 16;
+  d.TW = d.CW + 2;
+  d.ctiles = std::max(1, (d.PW + d.CW - 1) / d.CW);
+  d.n_tiles = ((d.PH + kRowTile - 1) / kRowTile) * d.ctiles;
   if ((size_t)n * d.n_tiles * 2 > m->sums_clips) {
     if (m->sums) { (void)hipFree(m->sums); m->sums = nullptr; }
     if (hipMalloc(&m->sums, (size_t)n * d.n_tiles * 2 * kC2 * sizeof(float)) != hipSuccess) { g_cerr = "hipMalloc failed"; return DYSF_E_NOMEM; }
     m->sums_clips = (size_t)n * d.n_tiles * 2;
   }
   d.act1 = (_Float16*)m->act1; d.sums = (float*)m->sums;
-  const size_t lds = (size_t)(kRowTile + 2) * d.AW * kPixPitch * sizeof(_Float16);
+  const size_t lds = f32 ? (size_t)(kRowTile + 2) * d.TW * kPixPitch32 * sizeof(float)
+                         : (size_t)(kRowTile + 2) * d.TW * kPixPitch * sizeof(_Float16);
   if (lds > 160 * 1024) { g_cerr = "feature map too wide for the LDS tile"; return DYSF_E_INVALID; }
-  if (!m->attr_set || true) {
-    if (hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)dysf_cnn_conv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  const int which = f32 ? 2 : (m->fused ? 0 : 1);
+  if (lds > m->lds_granted[which]) {  // raised once per kernel, and again only when a wider batch needs more
+    const void* fn = f32 ? (const void*)dysf_cnn_conv2_f32_kernel
+                         : (m->fused ? (const void*)dysf_cnn_conv2_kernel<true> : (const void*)dysf_cnn_conv2_kernel<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
     }
-    m->attr_set = true;
+    m->lds_granted[which] = lds;
   }
-  const dim3 grid2((d.PH + kRowTile - 1) / kRowTile, n);
-  if (m->fused) {
+  const dim3 grid2(d.n_tiles, n);
+  if (f32) {
+    hipLaunchKernelGGL(dysf_cnn_conv2_f32_kernel, grid2, dim3(512), lds, stream, d, d_frames, n);
+  } else if (m->fused) {
     hipLaunchKernelGGL(dysf_cnn_conv2_kernel<true>, grid2, dim3(512), lds, stream, d, d_frames, n);
   } else {
     hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);

@@ -90,6 +90,29 @@ struct FftGeom {
   DYSF_HD static constexpr int ns(int s) { return s == 0 ? 1 : (s == 1 ? 16 : 16 * radix(1)); }
 };
 
+// a + (-i) b and a - (-i) b without materialising (-i) b: the swap and the sign ride on the packed add's op_sel / neg
+// modifiers (the generic form below costs a v_xor and a v_mov per product)
+DYSF_HD cf add_mi(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));  // (ar + bi, ai - br)
+  return r;
+#else
+  return a + mul_mi(b);
+#endif
+}
+DYSF_HD cf sub_mi(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));  // (ar - bi, ai + br)
+  return r;
+#else
+  return a - mul_mi(b);
+#endif
+}
+DYSF_HD cd add_mi(cd a, cd b) { return a + mul_mi(b); }
+DYSF_HD cd sub_mi(cd a, cd b) { return a - mul_mi(b); }
+
 // ---- small DFTs on register arrays, elements at stride ST -------------------------------------
 template <int ST, class C>
 DYSF_HD void dft2(C* z) {
@@ -103,11 +126,10 @@ template <int ST, class C>
 DYSF_HD void dft4(C* z) {
   const C t0 = z[0] + z[2 * ST], t1 = z[0] - z[2 * ST];
   const C t2 = z[ST] + z[3 * ST], t3 = z[ST] - z[3 * ST];
-  const C m = mul_mi(t3);
   z[0] = t0 + t2;
-  z[ST] = t1 + m;       // t1 - i t3
+  z[ST] = add_mi(t1, t3);      // t1 - i t3
   z[2 * ST] = t0 - t2;
-  z[3 * ST] = t1 - m;   // t1 + i t3
+  z[3 * ST] = sub_mi(t1, t3);  // t1 + i t3
 }
 
 // forward radix-16 on 16 contiguous registers, output in natural order.

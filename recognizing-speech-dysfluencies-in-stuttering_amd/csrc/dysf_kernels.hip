@@ -241,8 +241,10 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
         // register array (a 32-way compare chain per value)
         float offer;
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
-        const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(offer), 0x140, 0xf, 0xf, false);
-        zm[i][h] = __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false));
+        // every lane of a row has a source lane under row_mirror / row_ror, so no "old" value is needed (mov_dpp
+        // leaves it undefined: no zero-initialising v_mov in front of each DPP move)
+        const int m = __builtin_amdgcn_mov_dpp(__float_as_int(offer), 0x140, 0xf, 0xf, true);
+        zm[i][h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
       }
     }
     zk[8] = z[8];
@@ -547,7 +549,9 @@ __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const K
 
 // =============================================================================================
 // Kernel A: PCM -> STFT power -> mel -> dB.  grid = (tile groups, clips); NT threads, NT/64 waves.
-template <int NC, int PCM, int NT, bool EX>
+// EX: float64 FFT (parity presets).  CH: chroma presets (piptrack peak picking, spectrogram rows kept for kernel C) and
+// the single-clip debug dumps; the throughput instantiation (CH = false) carries none of that code.
+template <int NC, int PCM, int NT, bool EX, bool CH>
 __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_mel_kernel(const KArgs a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L, FPW = G::FPW;
@@ -624,9 +628,9 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
       if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, a);
       else wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
       STAMP(1);  // prefetch issue + FFT
-      if (a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
+      if (CH && a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
       STAMP(7);  // piptrack
-      if (sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
+      if (CH && sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
 #pragma unroll
         for (int qq = 0; qq < FPW; ++qq) {
           const int t = f0 + wave * FPW + qq;
@@ -642,13 +646,13 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
     __syncthreads();  // S tile complete; every wave is done reading the PCM tile
     STAMP(2);  // barrier
     if (j + 1 < ntiles) bad |= pcm_commit<PCM, NT>(stage, tile, pbase, n32, r0, ngroups);
-    if (a.dbg_S) {
+    if (CH && a.dbg_S) {
       for (int i = tid; i < FPI * (NC + 1); i += NT) {
         const int f = i / (NC + 1), k = i % (NC + 1);
         if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
       }
     }
-    if (a.chroma) {  // flush this tile's peaks to the clip's list: one global atomic per tile
+    if (CH && a.chroma) {  // flush this tile's peaks to the clip's list: one global atomic per tile
       int* gcnt = a.ws_peak_cnt + clip;
       const int cnt = min(imisc[16], a.peak_tile_cap);
       __shared__ int gbase;
@@ -1395,12 +1399,17 @@ static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, h
 template <int NC>
 static hipError_t launch_stft_nc(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   constexpr int NT = stft_threads(NC);
-  if (a.parity) {
-    if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, true>, grid, NT, lds_bytes, s, a);
-    return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, true>, grid, NT, lds_bytes, s, a);
+  const bool ch = a.chroma || a.dbg_S;
+  if (a.parity) {  // parity presets are not the throughput path: one instantiation with everything in it
+    if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, true, true>, grid, NT, lds_bytes, s, a);
+    return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, true, true>, grid, NT, lds_bytes, s, a);
   }
-  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, false>, grid, NT, lds_bytes, s, a);
-  return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, false>, grid, NT, lds_bytes, s, a);
+  if (ch) {
+    if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, false, true>, grid, NT, lds_bytes, s, a);
+    return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, false, true>, grid, NT, lds_bytes, s, a);
+  }
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_I16, NT, false, false>, grid, NT, lds_bytes, s, a);
+  return launch_one(dysf_stft_mel_kernel<NC, DYSF_PCM_F32, NT, false, false>, grid, NT, lds_bytes, s, a);
 }
 
 template <int NC>

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_in_the_header():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.dysf_abi_version() == 1
+    assert L.dysf_abi_version() == rsd_amd._lib.ABI_VERSION == 2
 
 
 def test_presets_mirror_reference_constants():

@@ -46,7 +46,7 @@ def _pairs(golden_dir):
 
 
 def test_native_library_is_loaded():
-    assert rsd_amd._lib.lib().dysf_abi_version() == 1
+    assert rsd_amd._lib.lib().dysf_abi_version() == rsd_amd._lib.ABI_VERSION
     assert torch.cuda.is_available()
 
 
@@ -635,6 +635,54 @@ def test_fused_cnn_head_vs_torch_module(ex512):
     fused.close()
 
 
+def test_fused_cnn_head_float32_matches_cpu_module_on_every_clip(ex512):
+    """BASELINE configs[2] / SURVEY 8d Config 3: "CNN oracle = the same module on CPU fp32 (arg-max must match for fp32)".
+    conv2 on v_mfma_f32_16x16x4_f32 (exact fmaf chains), float32 activations: arg-max equal on EVERY clip, logits within
+    2e-5 of the CPU float32 module (summation order is the only difference)."""
+    from rsd_amd.classifier import CNNHead, FusedCNNHead
+    clips = np.stack([synth_clip(i) for i in range(64)])
+    pcm = torch.from_numpy(clips.reshape(-1)).cuda()
+    off = torch.arange(0, 65, dtype=torch.int64, device="cuda") * 48000
+    fr = ex512.extract_batch_device(pcm, off, 48000, pooled=False, frames=True)["frames"]
+    cnn = CNNHead()                      # float32 module on the CPU: the oracle
+    fused = FusedCNNHead(cnn, precision="f32")
+    with torch.no_grad():
+        want = cnn(fr.cpu())
+    got = fused(fr).cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(got.argmax(1), want.argmax(1))
+    fused.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fused_cnn_head_ragged_batch_equals_clip_by_clip_module(precision):
+    """BASELINE configs[4]: clips of different lengths in one launch.  Convolution padding, the pooling floor and the
+    global average follow every clip's OWN width: equal to the torch module run on each clip alone."""
+    from rsd_amd.classifier import CNNHead, FusedCNNHead
+    p = rsd_amd.FeatureParams(sr=22050, chroma=False, parity=False)
+    ex = rsd_amd.get_extractor(p, 0)
+    rng = np.random.default_rng(4321)
+    lens = (rng.uniform(1.0, 10.0, size=7) * 22050).astype(int).tolist() + [5000, 512 * 9]
+    clips = [synth_clip(200 + i, n=int(n), sr=22050) for i, n in enumerate(lens)]
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device="cuda")
+    fr = ex.extract_batch_device(pcm, off, max(lens), pooled=False, frames=True)["frames"]   # [9, 60, Tmax], zero past T_i
+    T = torch.tensor([p.n_frames(n) for n in lens], dtype=torch.int32, device="cuda")
+    cnn = CNNHead()
+    fused = FusedCNNHead(cnn, precision=precision)
+    got = fused(fr, cols=T).cpu()
+    with torch.no_grad():
+        want = torch.cat([cnn(fr[i:i + 1, :, :int(T[i])].cpu()) for i in range(len(lens))])
+    tol = (2e-5 if precision == "f32" else 2e-3) * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= tol, float((got - want).abs().max())
+    if precision == "f32":
+        assert torch.equal(got.argmax(1), want.argmax(1))
+    # the padded batch without per-clip widths is a different (wrong for ragged input) computation: the widths matter
+    assert float((fused(fr).cpu() - want).abs().max()) > tol
+    fused.close()
+
+
 def _run_bench(*flags, timeout=400):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -654,6 +702,12 @@ def test_bench_two_ranks_rehearsal():
     r = d["roofline"]   # frac follows from the SURVEY 8d bytes and the measured kernel time alone
     assert r["bytes_per_clip"] == 2 * 48000 + 4 * (120 * 301 + 240)
     assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 2e-4
+
+
+def test_bench_cnn_head_full_batch():
+    """BASELINE configs[2] at its full size through bench.py: 1024 clips, frame rows -> HIP CNN head, MFMA roofline entry."""
+    d = _run_bench("--head", "cnn", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--bank-workers", "2")
+    assert d["config"]["head"] == "cnn" and d["value"] > 0 and d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
 
 
 def test_bench_config4_two_ranks_rehearsal():

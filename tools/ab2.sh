@@ -1,0 +1,20 @@
+#!/bin/bash
+# Same-box A/B of library builds, per-kernel HIP-event times of the bench batch: tools/ab2.sh libA.so libB.so ... (repo-relative)
+for rep in 1 2; do
+for lib in "$@"; do
+  DYSF_LIB=$PWD/$lib python - "$lib" <<'PY'
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import rsd_amd
+from rsd_amd.synth import synth_bank
+bank = synth_bank(32, workers=1)
+pcm = torch.from_numpy(bank[np.arange(1024) % 32].reshape(-1)).cuda()
+off = torch.arange(0, 1025, dtype=torch.int64, device="cuda") * 48000
+ex = rsd_amd.FeatureExtractor(rsd_amd.BENCH_512, 0)
+for _ in range(10): ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=True)
+ex.kernel_timing(True); ts = []
+for _ in range(30):
+    ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=True); ts.append(ex.kernel_timing(True))
+print("%-28s stft %.1f us  mfcc %.1f us" % (os.path.basename(sys.argv[1]), 1e3 * np.median([t["stft_mel"] for t in ts]), 1e3 * np.median([t["mfcc"] for t in ts])))
+PY
+done; done
