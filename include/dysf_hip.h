@@ -125,6 +125,16 @@ int32_t dysf_extract_batch(DysfHandle* h, const void* pcm, int32_t pcm_type, con
                            int32_t n_clips, float* pooled, float* frames, int64_t frame_stride,
                            int32_t* status, int32_t* tuning);
 
+/*
+ * Per-file audio metrics of pipeline1.py:151-186 (the columns of output_results/per_file_analysis.csv), batched, DEVICE
+ * buffers: d_metrics [n_clips, 3] float32 = { snr_db (p1:151-165), spectral_flatness_mean (p1:168-174),
+ * high_freq_energy_ratio (p1:177-186) }.  The handle must have librosa's STFT defaults (n_fft 2048, hop 512, chroma on:
+ * REFERENCE_149), which is what spectral_flatness_mean transforms with.  Same input arguments as dysf_extract_batch_dev.
+ * A clip shorter than 25 ms has snr_db 0; an empty or non-finite clip has all three 0 (the reference's except -> 0.0).
+ */
+int32_t dysf_metrics_batch_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, const int64_t* d_offsets,
+                               int32_t n_clips, int64_t max_samples, float* d_metrics, void* stream);
+
 /* Kernel-level test hook: power spectrogram of one clip, device buffers.
  * d_S is [T, n_bins] float32 (frame-major).                                                           */
 int32_t dysf_debug_stft_power_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, int64_t n_samples,

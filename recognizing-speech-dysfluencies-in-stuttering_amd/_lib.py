@@ -18,7 +18,7 @@ SYMBOLS = (
     "dysf_abi_version", "dysf_last_error", "dysf_params_preset", "dysf_create", "dysf_destroy",
     "dysf_pooled_dim", "dysf_frame_rows", "dysf_num_frames", "dysf_debug_table",
     "dysf_extract_batch_dev", "dysf_extract_batch", "dysf_debug_stft_power_dev", "dysf_debug_logmel_dev",
-    "dysf_debug_timing", "dysf_debug_peaks",
+    "dysf_debug_timing", "dysf_debug_peaks", "dysf_metrics_batch_dev",
     "dysf_forest_last_error", "dysf_forest_create", "dysf_forest_destroy", "dysf_forest_predict_dev",
     "dysf_svc_last_error", "dysf_svc_create", "dysf_svc_destroy", "dysf_svc_predict_dev",
     "dysf_mlp_last_error", "dysf_mlp_create", "dysf_mlp_destroy", "dysf_mlp_forward_dev",
@@ -76,6 +76,7 @@ def lib():
     L.dysf_debug_table.restype = i64
     L.dysf_extract_batch_dev.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, i64, vp, vp, vp]
     L.dysf_extract_batch.argtypes = [vp, vp, i32, vp, i32, vp, vp, i64, vp, vp]
+    L.dysf_metrics_batch_dev.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
     L.dysf_debug_stft_power_dev.argtypes = [vp, vp, i32, i64, vp, vp]
     L.dysf_debug_logmel_dev.argtypes = [vp, vp, i32, i64, vp, vp]
     L.dysf_debug_timing.argtypes = [vp, i32, vp]

@@ -57,7 +57,7 @@ struct DysfHandle {
   int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   // workspace / staging
-  DevBuf ws_rich, ws_S, ws_stat;
+  DevBuf ws_rich, ws_S, ws_stat, ws_flat, ws_energy, ws_hf;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
@@ -154,7 +154,7 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
     (void)hipFree(h->d_window64); (void)hipFree(h->d_window64_i16); (void)hipFree(h->d_stage_tw64); (void)hipFree(h->d_post_tw64);
-    h->ws_S.release(); h->ws_stat.release();
+    h->ws_S.release(); h->ws_stat.release(); h->ws_flat.release(); h->ws_energy.release(); h->ws_hf.release();
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
@@ -271,7 +271,7 @@ static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::v
 // ------------------------------------------------------------------------------------------------
 static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t* d_offsets, int n_clips,
                    int64_t max_samples, float* d_pooled, float* d_frames, int64_t frame_stride, int32_t* d_status,
-                   int32_t* d_tuning, float* dbg_S, float* dbg_logmel, hipStream_t stream) {
+                   int32_t* d_tuning, float* dbg_S, float* dbg_logmel, hipStream_t stream, float* d_metrics = nullptr) {
   if (!h) return fail(DYSF_E_INVALID, "null handle");
   if (h->device < 0) return fail(DYSF_E_INVALID, "handle was created without a device (device < 0)");
   if (n_clips < 0 || max_samples < 0) return fail(DYSF_E_INVALID, "negative size");
@@ -288,7 +288,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
 
   KArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.pcm = d_pcm; a.hop = p.hop; a.sr = p.sr; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
+  a.pcm = d_pcm; a.pcm_type = pcm_type; a.hop = p.hop; a.sr = p.sr; a.kpad = t.kpad; a.n_mels = p.n_mels; a.n_mfcc = p.n_mfcc;
   a.pooled_dim = dysf_pooled_dim(h); a.frame_stride = frame_stride;
   a.dbg_S = dbg_S; a.dbg_logmel = dbg_logmel; a.dbg_stamps = h->dbg_stamps;
   // power_to_db of a floor cell: float32(10) * float32(log10(amin)), the reference's two roundings (-100 for 1e-10)
@@ -358,8 +358,13 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.ws_S_stride = p.chroma ? t_max * (int64_t)a.s_stride : 0;
   const bool need_stat = p.parity && d_pooled && !d_frames;  // kernel B re-reads the frame rows for NumPy-order statistics
   a.stat_stride = need_stat ? ((t_max + 3) & ~(int64_t)3) : 0;
+  // metrics launches (pipeline1.py:151-174): per-frame spectral flatness and the 25 ms / 10 ms frame energies of snr_db
+  const int snr_fl = (int)(0.025 * p.sr), snr_hop = (int)(0.010 * p.sr);
+  const long long hf_M = d_metrics ? hf_ratio_fft_size(max_samples) : 0;
+  a.energy_stride = d_metrics ? std::max<int64_t>(1, max_samples >= snr_fl ? 1 + (max_samples - snr_fl) / std::max(1, snr_hop) : 1) : 0;
   const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4 +
-                          (size_t)a.ws_S_stride * 4 + (size_t)a.stat_stride * 3 * p.n_mfcc * 4;
+                          (size_t)a.ws_S_stride * 4 + (size_t)a.stat_stride * 3 * p.n_mfcc * 4 +
+                          (d_metrics ? (size_t)(t_max + a.energy_stride) * 4 + hf_ratio_bytes_per_clip(hf_M) : 0);
   // a sub-batch is gridDim.y of kernel A: at most 65535 clips
   const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_clips, 65535), (int64_t)(h->ws_budget / per_clip)));
   if (int rc = h->ws_logmel.reserve((size_t)sub * a.ws_logmel_stride * 4)) return rc;
@@ -372,8 +377,15 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   if (p.rich) { if (int rc = h->ws_rich.reserve((size_t)sub * a.ws_rich_stride * 14 * 4)) return rc; }
   if (p.chroma) { if (int rc = h->ws_S.reserve((size_t)sub * a.ws_S_stride * 4)) return rc; }
   if (need_stat) { if (int rc = h->ws_stat.reserve((size_t)sub * a.stat_stride * 3 * p.n_mfcc * 4)) return rc; }
+  if (d_metrics) {
+    if (int rc = h->ws_flat.reserve((size_t)sub * t_max * 4)) return rc;
+    if (int rc = h->ws_energy.reserve((size_t)sub * a.energy_stride * 4)) return rc;
+    if (int rc = h->ws_hf.reserve((size_t)sub * hf_ratio_bytes_per_clip(hf_M))) return rc;
+  }
   a.ws_S = (float*)h->ws_S.p;
   a.ws_stat = (float*)h->ws_stat.p;
+  a.ws_flat = d_metrics ? (float*)h->ws_flat.p : nullptr;
+  a.ws_energy = (float*)h->ws_energy.p;
   a.ws_rich = (float*)h->ws_rich.p;
   a.ws_logmel = (float*)h->ws_logmel.p;
   a.ws_peak_mag = (float*)h->ws_peak_mag.p;
@@ -409,6 +421,11 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
     h->ws_clean = a.self_clean != 0; h->ws_stream = stream;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[2], stream));
+    if (d_metrics) {   // (reads the non-finite flag kernel B leaves in place for chroma presets)
+      a.metrics = d_metrics + (size_t)c0 * 3;
+      HIPCHK(launch_metrics(a, dim3(nc), stream));
+      HIPCHK(launch_hf_ratio(a, nc, hf_M, h->ws_hf.p, stream));
+    }
     if (p.chroma) HIPCHK(launch_chroma(a, dim3(nc), stream));
     if (p.rich) {
       a.rstride = rstride_c;
@@ -467,6 +484,18 @@ int32_t dysf_extract_batch(DysfHandle* h, const void* pcm, int32_t pcm_type, con
   if (status) HIPCHK(hipMemcpy(status, h->st_status.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
   if (tuning) HIPCHK(hipMemcpy(tuning, h->st_tuning.p, (size_t)n_clips * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+int32_t dysf_metrics_batch_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type, const int64_t* d_offsets, int32_t n_clips,
+                               int64_t max_samples, float* d_metrics, void* stream) {
+  if (!h || !d_metrics) return fail(DYSF_E_INVALID, "null argument");
+  const DysfParams& p = h->t.p;
+  // librosa.stft defaults are what spectral_flatness_mean (pipeline1.py:170) transforms with; the kernels that zero the
+  // per-clip flag words themselves (presets without chroma) would do so before the metrics kernel reads them
+  if (p.n_fft != 2048 || p.hop != 512 || !p.chroma)
+    return fail(DYSF_E_INVALID, "metrics need a handle with librosa's STFT defaults (n_fft 2048, hop 512) and chroma on, e.g. REFERENCE_149");
+  return run_dev(h, d_pcm, pcm_type, d_offsets, n_clips, max_samples, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                 (hipStream_t)stream, d_metrics);
 }
 
 int64_t dysf_debug_peaks(DysfHandle* h, float* mag, int32_t* bin, int64_t cap) {

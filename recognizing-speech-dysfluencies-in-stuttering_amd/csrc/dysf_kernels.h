@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/dysf_hip.h"
 
 namespace dysf {
@@ -12,6 +14,7 @@ struct KArgs {
   const void* pcm;
   const long long* offsets;
   int n_clips;
+  int pcm_type;      // DYSF_PCM_I16 / DYSF_PCM_F32 (the STFT kernels are templated on it; the metrics kernel reads it)
   // outputs (any may be null)
   float* pooled;
   int pooled_dim;
@@ -63,6 +66,10 @@ struct KArgs {
   float* ws_S;                 // chroma presets: [clip][T_max][s_stride] power spectrogram (kernel A -> kernel C)
   long long ws_S_stride;       // floats per clip
   int s_stride;                // floats per spectrum row = n_bins rounded up to 16 (padding columns are zero)
+  float* ws_flat;              // metrics launches: [clip][t_max] spectral flatness of every frame (kernel A -> metrics kernel)
+  float* ws_energy;            // metrics launches: [clip][energy_stride] 25 ms frame energies of snr_db
+  long long energy_stride;
+  float* metrics;              // [clip][3] snr_db, spectral_flatness_mean, high_freq_energy_ratio (pipeline1.py:151-186)
   float* ws_stat;              // parity presets without a frames output: [clip][3*n_mfcc][stat_stride] frame rows
   long long stat_stride;
   int self_clean;           // kernel B zeroes ws_clipmax / ws_flags after reading them (presets without chroma)
@@ -93,6 +100,11 @@ constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s);
+hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s);
+// high_freq_energy_ratio (dysf_hfratio.hip): chirp-z transform of every whole clip on FFTs of size M
+long long hf_ratio_fft_size(long long max_samples);
+size_t hf_ratio_bytes_per_clip(long long M);
+hipError_t launch_hf_ratio(const KArgs& a, int n_clips, long long M, void* workspace, hipStream_t s);
 hipError_t launch_rich(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 
 }  // namespace dysf

@@ -576,7 +576,8 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
   const long long n = a.offsets[clip + 1] - off;
   const int T = (int)(1 + n / a.hop);
   const int ti0 = blockIdx.x * a.tiles_per_wg;
-  if (n <= 0 || T < 9 || T > a.t_max || ti0 * FPI >= T) return;  // rejected clips and empty tile groups (uniform exit)
+  // rejected clips and empty tile groups (uniform exit); a metrics launch still wants the spectral flatness of short clips
+  if (n <= 0 || (T < 9 && !(CH && a.ws_flat)) || T > a.t_max || ti0 * FPI >= T) return;
   const int ntiles = min(a.tiles_per_wg, (T - ti0 * FPI + FPI - 1) / FPI);
 
   float* wregion = regions + wave * a.rstride;
@@ -630,6 +631,20 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
       STAMP(1);  // prefetch issue + FFT
       if (CH && a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
       STAMP(7);  // piptrack
+      if (CH && a.ws_flat) {
+        // librosa.feature.spectral_flatness of this frame (pipeline1.py:168-174): geometric over arithmetic mean of
+        // max(1e-10, |D|**2) across the bins
+        float slog = 0.f, ssum = 0.f;
+        for (int k = lane % L; k <= NC; k += L) {
+          const float v = fmaxf(1e-10f, srow_own[k]);
+          slog += logf(v); ssum += v;
+        }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) { slog += __shfl_xor(slog, o); ssum += __shfl_xor(ssum, o); }
+        const int t = f0 + wave * FPW + q;
+        if (lane % L == 0 && t < T)
+          a.ws_flat[(size_t)clip * a.t_max + t] = div_rn(expf(slog / (float)(NC + 1)), ssum / (float)(NC + 1));
+      }
       if (CH && sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
 #pragma unroll
         for (int qq = 0; qq < FPW; ++qq) {
@@ -1378,6 +1393,84 @@ __global__ __launch_bounds__(NT, 2) void dysf_rich_kernel(const KArgs a) {
   }
 }
 
+// =============================================================================================
+// Metrics kernel (pipeline1.py:151-174): snr_db from the PCM and the mean of the per-frame spectral flatness kernel A left
+// in the workspace.  One workgroup per clip.
+//   snr_db: 25 ms frames every 10 ms without padding, float32 frame energies, the frames whose energy lies below the 25th
+//   percentile (NumPy's linear interpolation between the two order statistics) are noise;
+//   10 * log10(mean energy / (mean noise energy + 1e-10)); 0 when the clip is shorter than a frame or nothing is noise.
+template <int NT>
+__global__ __launch_bounds__(NT) void dysf_metrics_kernel(const KArgs a) {
+  constexpr int NW = NT / 64;
+  __shared__ int sm_i[400];
+  __shared__ double sm_d[NW * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int clip = blockIdx.x;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  float* out = a.metrics + (size_t)clip * 3;
+  const bool pcm16 = a.pcm_type == DYSF_PCM_I16;
+  const int FL = (int)(0.025 * (double)a.sr), HP = (int)(0.010 * (double)a.sr);
+  auto sample = [&](long long i) -> float {
+    return pcm16 ? (float)((const short*)a.pcm)[off + i] * (1.0f / 32768.0f) : ((const float*)a.pcm)[off + i];
+  };
+  // ---- spectral_flatness_mean
+  float flat = 0.f;
+  if (n > 0 && T <= a.t_max && !a.ws_flags[clip]) {
+    double s = 0.0;
+    for (int t = tid; t < T; t += NT) s += (double)a.ws_flat[(size_t)clip * a.t_max + t];
+    s = wave_sum(s);
+    if (lane == 0) sm_d[wave] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < NW; ++w) tot += sm_d[w];
+    flat = (float)(tot / (double)T);
+    __syncthreads();
+  }
+  // ---- snr_db
+  float snr = 0.f;
+  const long long nfr = (n >= FL) ? 1 + (n - FL) / HP : 0;
+  if (nfr > 0 && nfr <= a.energy_stride && !a.ws_flags[clip]) {
+    float* en = a.ws_energy + (size_t)clip * a.energy_stride;
+    for (int f = tid; f < (int)nfr; f += NT) {
+      // (NumPy sums the float32 squares pairwise in float32; float64 here: the results agree to ~1e-7 relative)
+      double acc = 0.0;
+      for (int i = 0; i < FL; ++i) { const float x = sample((long long)f * HP + i); acc += (double)mul_rn(x, x); }
+      const float tot = (float)acc;
+      en[f] = tot;
+    }
+    __syncthreads();
+    const double vidx = 0.25 * (double)(nfr - 1);
+    const int lo = (int)floor(vidx);
+    const int hi = lo + 1 < (int)nfr ? lo + 1 : (int)nfr - 1;
+    const double g = vidx - (double)lo;
+    const float e_lo = block_select<NT>(en, (int)nfr, lo, sm_i + 128, sm_i);
+    const float e_hi = block_select<NT>(en, (int)nfr, hi, sm_i + 128, sm_i);
+    const float d32 = sub_rn(e_hi, e_lo);
+    const double p25 = (g >= 0.5) ? (double)e_hi - (double)d32 * (1.0 - g) : (double)e_lo + (double)d32 * g;
+    double s_all = 0.0, s_noise = 0.0, c_noise = 0.0;
+    for (int f = tid; f < (int)nfr; f += NT) {
+      const float e = en[f];
+      s_all += (double)e;
+      if ((double)e < p25) { s_noise += (double)e; c_noise += 1.0; }
+    }
+    s_all = wave_sum(s_all); s_noise = wave_sum(s_noise); c_noise = wave_sum(c_noise);
+    if (lane == 0) { sm_d[wave] = s_all; sm_d[NW + wave] = s_noise; sm_d[2 * NW + wave] = c_noise; }
+    __syncthreads();
+    if (tid == 0) {
+      double A = 0.0, B = 0.0, Cn = 0.0;
+      for (int w = 0; w < NW; ++w) { A += sm_d[w]; B += sm_d[NW + w]; Cn += sm_d[2 * NW + w]; }
+      if (Cn > 0.0) {
+        const float sig = (float)(A / (double)nfr), noi = (float)(B / Cn);
+        const float ratio = div_rn(sig, add_rn(noi, 1e-10f));
+        snr = mul_rn(10.0f, (float)log10((double)ratio));
+      }
+    }
+  }
+  if (tid == 0) { out[0] = snr; out[1] = flat; }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
@@ -1443,6 +1536,11 @@ hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t 
   if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
   return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);
 }
+hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(dysf_metrics_kernel<256>, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL(dysf_chroma_kernel<512>, grid, dim3(512), 0, s, a);
   return hipGetLastError();

@@ -45,8 +45,21 @@ EDGE_CLIPS = ("M_0091_11y4m_1 (mp3cut.net) (2).wav", "M_1107_38y0m_1 (mp3cut.net
 AUDIO_EXTS = (".wav", ".mp3", ".flac", ".m4a", ".ogg")  # pipeline1.py:77
 
 
+def reference_metrics():
+    """stem -> (snr_after, flat_after, hf_after) from the reference's output_results/per_file_analysis.csv: the metrics of
+    pipeline1.py:151-186 evaluated on the cleaned clip, i.e. on clear_audio/<stem>.wav."""
+    out = {}
+    with open(os.path.join(REF, "output_results", "per_file_analysis.csv")) as f:
+        for r in csv.DictReader(f):
+            out[r["file"].rsplit(".", 1)[0]] = (float(r["snr_after"]), float(r["flat_after"]), float(r["hf_after"]))
+    return out
+
+
 def validate_all():
     wavs = sorted(glob.glob(os.path.join(REF, "clear_audio", "*.wav")))
+    ref_m = reference_metrics()
+    m_err = np.zeros(3)
+    m_n = 0
     blocks = {"mfcc_stats": (0, 40), "delta_stats": (40, 80), "delta2_stats": (80, 120),
               "chroma_stats": (120, 144), "text": (144, 149)}
     bmax = {k: 0.0 for k in blocks}
@@ -65,6 +78,12 @@ def validate_all():
             bmax[k] = max(bmax[k], float(d[a:b].max()))
         rows.append((stem, float(d.max()), int(d.argmax()), len(pcm)))
         lengths[w] = len(pcm)
+        if stem in ref_m:
+            got = O.audio_metrics(O.pcm16_to_float(pcm), sr)
+            want = np.array(ref_m[stem])
+            m_err = np.maximum(m_err, [abs(got[0] - want[0]), abs(got[1] - want[1]) / max(abs(want[1]), 1e-12),
+                                       abs(got[2] - want[2]) / max(abs(want[2]), 1e-12)])
+            m_n += 1
     diffs = np.array([r[1] for r in rows])
     rec = {
         "what": "oracle/dysf_oracle.py extract_features vs reference cache_features/*_clean_feats.npy",
@@ -76,6 +95,9 @@ def validate_all():
         "block_max_abs_diff": bmax,
         "worst_clips": [dict(stem=r[0], max_abs_diff=r[1], index=r[2], n_samples=r[3])
                         for r in sorted(rows, key=lambda r: -r[1])[:5]],
+        "metrics": {"what": "oracle audio_metrics vs per_file_analysis.csv (snr_after, flat_after, hf_after)", "n_clips": m_n,
+                    "snr_db_max_abs_diff": float(m_err[0]), "flatness_max_rel_diff": float(m_err[1]),
+                    "hf_ratio_max_rel_diff": float(m_err[2])},
         "numpy": np.__version__,
     }
     import scipy
@@ -96,12 +118,15 @@ def copy_pairs(lengths):
     for name in EDGE_CLIPS:
         chosen += [w for w in lengths if os.path.basename(w) == name]
     index = []
+    ref_m = reference_metrics()
     for i, w in enumerate(chosen):
         stem = os.path.basename(w)[:-4]
         shutil.copyfile(w, os.path.join(out, f"{i:02d}.wav"))
         shutil.copyfile(os.path.join(REF, "cache_features", stem + "_clean_feats.npy"),
                         os.path.join(out, f"{i:02d}.npy"))
-        index.append({"id": f"{i:02d}", "reference_stem": stem, "n_samples": lengths[w]})
+        index.append({"id": f"{i:02d}", "reference_stem": stem, "n_samples": lengths[w],
+                      # per_file_analysis.csv: snr_after, flat_after, hf_after of this clip (pipeline1.py:394-396)
+                      "metrics_after": list(ref_m[stem]) if stem in ref_m else None})
     with open(os.path.join(out, "index.json"), "w") as f:
         json.dump(index, f, indent=1)
 
@@ -113,11 +138,12 @@ def export_all(lengths):
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
     index = []
+    ref_m = reference_metrics()
     for i, w in enumerate(sorted(lengths)):
         stem = os.path.basename(w)[:-4]
         shutil.copyfile(w, os.path.join(out, f"{i:03d}.wav"))
         shutil.copyfile(os.path.join(REF, "cache_features", stem + "_clean_feats.npy"), os.path.join(out, f"{i:03d}.npy"))
-        index.append({"id": f"{i:03d}", "stem": stem, "n_samples": lengths[w]})
+        index.append({"id": f"{i:03d}", "stem": stem, "n_samples": lengths[w], "metrics_after": list(ref_m[stem]) if stem in ref_m else None})
     with open(os.path.join(out, "index.json"), "w") as f:
         json.dump(index, f)
 

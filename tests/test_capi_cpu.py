@@ -135,6 +135,8 @@ def test_head_and_resampler_constructors_validate_before_touching_the_gpu():
                                 ctypes.byref(h)) < 0 and b"children" in L.dysf_forest_last_error()
     # CNN and resampler
     f32 = np.ones(64 * 32 * 9, np.float32)
-    assert L.dysf_cnn_create(0, 0, ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ctypes.byref(h)) < 0
+    assert L.dysf_cnn_create(0, 0, 0, ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ctypes.byref(h)) < 0
+    assert L.dysf_cnn_create(0, 3, 7, ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ptr(f32), ctypes.byref(h)) < 0
+    assert b"precision" in L.dysf_cnn_last_error()
     assert L.dysf_resampler_create(0, 0, 441, ptr(one), 8, 0, ctypes.byref(h)) < 0 and b"shape" in L.dysf_resampler_last_error()
     assert not h.value

@@ -171,6 +171,34 @@ def test_more_clips_than_one_grid_dimension(ex512):
     assert np.array_equal(po[-1].cpu().numpy(), want)
 
 
+def test_audio_metrics_match_reference_csv_and_oracle(golden_dir):
+    """pipeline1.py:151-186 on the GPU against (i) the reference's own per_file_analysis.csv values for the committed clips
+    (snr_after, flat_after, hf_after) and (ii) the oracle on synthetic clips of awkward lengths (prime, shorter than one
+    25 ms frame, silent).  Tolerances: snr 2e-4 dB, flatness 5e-4 relative (float32 log / exp of two libraries),
+    high-frequency ratio 2e-5 relative (float32 FFT of a different factorisation)."""
+    idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
+    clips, want = [], []
+    for (cid, pcm, sr, gold), e in zip(_pairs(golden_dir), idx):
+        assert e["metrics_after"] is not None
+        clips.append(pcm); want.append(e["metrics_after"])
+    got = rsd_amd.audio_metrics_batch(clips, 16000)
+    want = np.array(want)
+    assert np.abs(got[:, 0] - want[:, 0]).max() <= 2e-4, np.abs(got[:, 0] - want[:, 0]).max()
+    assert (np.abs(got[:, 1] - want[:, 1]) / want[:, 1]).max() <= 5e-4
+    assert (np.abs(got[:, 2] - want[:, 2]) / want[:, 2]).max() <= 2e-5
+    # the reference-shaped single-clip functions
+    y = O.pcm16_to_float(clips[3])
+    assert abs(rsd_amd.snr_db(y) - want[3, 0]) <= 2e-4 and abs(rsd_amd.high_freq_energy_ratio(y, 16000) - want[3, 2]) <= 2e-5 * want[3, 2]
+    assert rsd_amd.snr_db(None) == 0.0
+    odd = [synth_clip(5, n=n) for n in (7919, 48000, 30011, 300, 4099)] + [np.zeros(9000, np.int16)]
+    got = rsd_amd.audio_metrics_batch(odd, 16000)
+    for i, c in enumerate(odd):
+        w = O.audio_metrics(O.pcm16_to_float(c), 16000)
+        assert abs(got[i, 0] - w[0]) <= 2e-4, (i, got[i], w)
+        assert abs(got[i, 1] - w[1]) <= 5e-4 * max(w[1], 1e-6), (i, got[i], w)
+        assert abs(got[i, 2] - w[2]) <= 2e-5 * max(w[2], 1e-6), (i, got[i], w)
+
+
 def test_int16_and_float32_inputs_agree(ex149, ex512):
     y = synth_clip(2, n=20000)
     for ex in (ex149, ex512):

@@ -56,6 +56,18 @@ def test_log10_f32_is_correctly_rounded():
     assert got.dtype == np.float32 and (np.abs(got.astype(np.float64) - exact) <= 0.5000001 * np.spacing(np.abs(got))).all()
 
 
+def test_oracle_metrics_reproduce_the_reference_csv(golden_dir):
+    """snr_db / spectral_flatness_mean / high_freq_energy_ratio (pipeline1.py:151-186) against the reference's own
+    per_file_analysis.csv values for the committed clips, and the 888-clip record."""
+    rec = json.load(open(os.path.join(golden_dir, "validate_888.json")))["metrics"]
+    assert rec["n_clips"] == 888 and rec["snr_db_max_abs_diff"] <= 5e-5 and rec["flatness_max_rel_diff"] <= 5e-4
+    assert rec["hf_ratio_max_rel_diff"] <= 1e-6
+    for e, pcm, sr, gold in _pairs(golden_dir):
+        got = O.audio_metrics(O.pcm16_to_float(pcm), sr)
+        want = np.array(e["metrics_after"])
+        assert abs(got[0] - want[0]) <= 5e-5 and abs(got[1] - want[1]) <= 5e-4 * want[1] and abs(got[2] - want[2]) <= 1e-6 * want[2]
+
+
 def test_config1_clip_is_among_the_fixtures(golden_dir):
     idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
     assert any(e["reference_stem"] == "F_0050_10y9m_1 (mp3cut.net)10" and e["n_samples"] == 53951 for e in idx)
