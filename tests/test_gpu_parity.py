@@ -171,6 +171,36 @@ def test_more_clips_than_one_grid_dimension(ex512):
     assert np.array_equal(po[-1].cpu().numpy(), want)
 
 
+def test_deployed_predictor_wav_to_label_string(golden_dir):
+    """The reference's serve path, main1.py:965-990, as one call chain: WAV file -> load_audio -> extract_features ->
+    guard on n_features_in_ -> scaler.transform -> rf.predict / predict_proba -> LabelEncoder.inverse_transform.
+    Expected label = scikit-learn's own prediction (the fitted forest of pipeline1.py:496, tests/golden/forest_after.npz)
+    on the reference's CACHED vector of the same clip."""
+    from rsd_amd.classifier import RandomForestHead
+    c = np.load(os.path.join(golden_dir, "classifier_after.npz"), allow_pickle=False)
+    f = np.load(os.path.join(golden_dir, "forest_after.npz"), allow_pickle=False)
+    classes = [str(x) for x in c["classes"]]                      # LabelEncoder.classes_ (sorted label strings)
+    rf = RandomForestHead.from_npz(os.path.join(golden_dir, "forest_after.npz"), classes=classes)
+    d = os.path.join(golden_dir, "ref_pairs")
+    n = 0
+    for e in json.load(open(os.path.join(d, "index.json"))):
+        gold = np.load(os.path.join(d, e["id"] + ".npy"))
+        rows = np.nonzero((c["X"] == gold[None, :]).all(axis=1))[0]   # this clip's row(s) in the 905 x 149 training matrix
+        assert len(rows) >= 1, e
+        want_label = classes[int(f["expected_pred"][rows[0]])]
+        y, sr = rsd_amd.load_audio(os.path.join(d, e["id"] + ".wav"))          # main1.py:971
+        feats = rsd_amd.extract_features(y, sr, "")                             # main1.py:975
+        assert feats.shape[0] == rf.n_features_in_                              # main1.py:976-981
+        x = torch.from_numpy(feats.reshape(1, -1)).cuda()
+        pred = int(rf.predict(x)[0])                                            # main1.py:987-988 (scaler inside the head)
+        proba = rf.predict_proba(x)[0].cpu().numpy()                            # main1.py:989
+        assert classes[pred] == want_label, (e["id"], classes[pred], want_label)  # main1.py:990
+        assert np.abs(proba - f["expected_proba"][rows[0]]).max() <= 0.0051      # at most one of 200 trees may differ
+        n += 1
+    assert n == 17
+    rf.close()
+
+
 def test_audio_metrics_match_reference_csv_and_oracle(golden_dir):
     """pipeline1.py:151-186 on the GPU against (i) the reference's own per_file_analysis.csv values for the committed clips
     (snr_after, flat_after, hf_after) and (ii) the oracle on synthetic clips of awkward lengths (prime, shorter than one
