@@ -322,19 +322,24 @@ def main():
         # PCIe-inclusive rate (N = 1): host int16 -> H2D overlapped with the kernels -> pooled rows back on the host
         host_rate = None
         if world == 1 and not args.no_host_rate and args.config == 2 and cnn is None:
-            from rsd_amd.ingest import StreamingExtractor
-            n_host = 8192
-            flat = np.tile(bank.reshape(-1), n_host // BATCH)
+            from rsd_amd.ingest import StreamingExtractor, pinned_empty
+            n_host = 16384
             hoff = np.arange(n_host + 1, dtype=np.int64) * N_SAMPLES
-            se = StreamingExtractor(ex, chunk_clips=2048)
-            se.run(flat[: 2048 * N_SAMPLES], hoff[:2049])
-            th = time.perf_counter()
-            out = se.run(flat, hoff)
-            th = time.perf_counter() - th
-            assert int(np.abs(out["status"]).sum()) == 0
-            host_rate = {"clips_per_s": round(n_host / th, 1), "pcm_gb_per_s": round(n_host * N_SAMPLES * 2 / th / 1e9, 2),
-                         "h2d_gb_per_s": round(se.h2d_gbs, 2) if getattr(se, "h2d_gbs", None) else None,
-                         "clips": n_host, "path": se.describe() if hasattr(se, "describe") else "pinned staging, double-buffered H2D"}
+            host_rate = {"clips": n_host}
+            # (i) the producer decodes into page-locked memory (pinned_empty): H2D starts straight from it;
+            # (ii) an ordinary pageable array, page-locked for the call by hipHostRegister (its cost is inside the time)
+            for name, flat in (("pinned_source", pinned_empty(n_host * N_SAMPLES)), ("registered_pageable_source", np.empty(n_host * N_SAMPLES, np.int16))):
+                flat.reshape(n_host // BATCH, -1)[:] = bank.reshape(1, -1)
+                se = StreamingExtractor(ex, chunk_clips=2048)
+                se.run(flat[: 4096 * N_SAMPLES], hoff[:4097])
+                th = time.perf_counter()
+                o2 = se.run(flat, hoff)
+                th = time.perf_counter() - th
+                assert int(np.abs(o2["status"]).sum()) == 0
+                host_rate[name] = {"clips_per_s": round(n_host / th, 1), "pcm_gb_per_s": round(n_host * N_SAMPLES * 2 / th / 1e9, 2),
+                                   "h2d_gb_per_s_on_the_copy_stream": round(se.h2d_gbs, 2) if se.h2d_gbs else None, "path": se.describe()}
+                del flat
+            host_rate["clips_per_s"] = host_rate["pinned_source"]["clips_per_s"]
     assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3)
     assert bool(torch.isfinite(all_logits).all())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)

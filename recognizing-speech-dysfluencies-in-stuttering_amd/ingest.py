@@ -47,14 +47,36 @@ def pack_wavs(paths: Sequence[str], sr: int) -> Tuple[np.ndarray, np.ndarray, Li
     return flat, offsets, ok
 
 
-class StreamingExtractor:
-    """Chunks of clips flow host -> device -> host through two pinned staging buffers and two device buffers:
-    the H2D copy of chunk i+1 runs on a copy stream while the kernels of chunk i run on the compute stream."""
+def pinned_empty(n: int, dtype=np.int16) -> np.ndarray:
+    """A page-locked host array (torch's pinned allocator = hipHostMalloc): what a reader should decode PCM into, so that
+    the H2D copies of ``StreamingExtractor`` start straight from it."""
+    import torch
+    t = torch.empty(int(n), dtype={np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]).pin_memory()
+    a = t.numpy()
+    _PINNED_OWNERS[a.ctypes.data] = t     # keeps the allocation alive as long as the process (views carry no owner)
+    return a
 
-    def __init__(self, extractor, chunk_clips: int = 1024, copy_threads: int = 4):
+
+_PINNED_OWNERS = {}
+
+
+class StreamingExtractor:
+    """Chunks of clips flow host -> device -> host: the H2D copy of chunk i+1 runs on a copy stream while the kernels of
+    chunk i run on the compute stream, into two device buffers.  The copies start from the CALLER's buffer: it is used in
+    place if it is page-locked already (``pinned_empty``) or is page-locked for the duration of the call
+    (hipHostRegister; ``register=False`` or a failed registration falls back to two pinned staging buffers filled by
+    ``copy_threads`` host threads, which caps the rate at the host's memcpy speed)."""
+
+    def __init__(self, extractor, chunk_clips: int = 1024, copy_threads: int = 4, register: bool = True):
         self.ex = extractor
         self.chunk = int(chunk_clips)
         self.copy_threads = max(1, int(copy_threads))   # host threads that fill the pinned staging buffer
+        self.register = bool(register)
+        self.path = ""
+        self.h2d_gbs = None
+
+    def describe(self) -> str:
+        return self.path
 
     def _stage_copy(self, pool, dst: np.ndarray, src: np.ndarray):
         """dst[:] = src with the work cut into slices for the thread pool (NumPy's copy releases the GIL); one thread
@@ -69,11 +91,26 @@ class StreamingExtractor:
         for f in futs:
             f.result()
 
+    @staticmethod
+    def _page_locked_view(pcm: np.ndarray, allow_register: bool):
+        """(torch view of pcm that H2D copies may start from, registered?) or (None, False)."""
+        import torch
+        if not pcm.flags["C_CONTIGUOUS"] or not pcm.flags["WRITEABLE"]:
+            return None, False
+        t = torch.from_numpy(pcm)
+        if t.is_pinned():
+            return t, False
+        if allow_register and pcm.nbytes > 0:
+            rc = torch.cuda.cudart().cudaHostRegister(pcm.ctypes.data, pcm.nbytes, 0)
+            if int(rc) == 0:
+                return t, True
+        return None, False
+
     def run(self, pcm: np.ndarray, offsets: np.ndarray) -> Dict[str, np.ndarray]:
+        import time
         import torch
         from concurrent.futures import ThreadPoolExecutor
         assert pcm.dtype == np.int16 and offsets.dtype == np.int64
-        pool = ThreadPoolExecutor(self.copy_threads) if self.copy_threads > 1 else None
         dev = torch.device("cuda", self.ex.device)
         n = len(offsets) - 1
         bounds = [(i, min(n, i + self.chunk)) for i in range(0, n, self.chunk)]
@@ -81,45 +118,72 @@ class StreamingExtractor:
         status = torch.empty(n, dtype=torch.int32).pin_memory()
         if n == 0:
             return {"pooled": pooled.numpy(), "status": status.numpy()}
+        torch.cuda.set_device(dev)
+        direct, registered = self._page_locked_view(pcm, self.register)
+        self.path = ("H2D straight from the caller's buffer (" + ("page-locked by hipHostRegister for the call" if registered
+                     else "already page-locked") + "), double-buffered on the device") if direct is not None else \
+            f"pinned staging buffers filled by {self.copy_threads} host threads, double-buffered H2D"
+        pool = ThreadPoolExecutor(self.copy_threads) if (direct is None and self.copy_threads > 1) else None
         max_chunk = max(int(offsets[b] - offsets[a]) for a, b in bounds)
         max_chunk = (max_chunk + 7) // 8 * 8 + 8
-        host = [torch.empty(max_chunk, dtype=torch.int16).pin_memory() for _ in range(2)]
+        host = [torch.empty(max_chunk, dtype=torch.int16).pin_memory() for _ in range(2)] if direct is None else None
         dpcm = [torch.empty(max_chunk, dtype=torch.int16, device=dev) for _ in range(2)]
         doff = [torch.empty(self.chunk + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+        rel_all = torch.empty(n + len(bounds), dtype=torch.int64).pin_memory()   # every chunk's relative offsets, pinned
         copy_s, comp_s = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
         ready = [torch.cuda.Event() for _ in range(2)]   # H2D of slot done
         free = [torch.cuda.Event() for _ in range(2)]    # kernels reading slot done
         host_free = [None, None]
+        h2d_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        h2d_bytes = 0
 
         def stage(ci):
+            nonlocal h2d_bytes
             a, b = bounds[ci]
             s = ci & 1
             lo, hi = int(offsets[a]), int(offsets[b])
-            if host_free[s] is not None:
-                host_free[s].synchronize()            # the previous H2D out of this pinned buffer has finished
-            self._stage_copy(pool, host[s][: hi - lo].numpy(), pcm[lo:hi])
-            rel = torch.from_numpy((offsets[a:b + 1] - lo).astype(np.int64))
+            if direct is None:
+                if host_free[s] is not None:
+                    host_free[s].synchronize()            # the previous H2D out of this pinned buffer has finished
+                self._stage_copy(pool, host[s][: hi - lo].numpy(), pcm[lo:hi])
+                src = host[s][: hi - lo]
+            else:
+                src = direct[lo:hi]
+            rel = rel_all[a + ci: b + ci + 1]
+            rel.copy_(torch.from_numpy(offsets[a:b + 1] - lo))
             with torch.cuda.stream(copy_s):
                 copy_s.wait_event(free[s])            # the kernels of the chunk that used this slot are done
-                dpcm[s][: hi - lo].copy_(host[s][: hi - lo], non_blocking=True)
+                if ci == 0:
+                    h2d_ev[0].record(copy_s)
+                dpcm[s][: hi - lo].copy_(src, non_blocking=True)
                 doff[s][: b - a + 1].copy_(rel, non_blocking=True)
                 ready[s].record(copy_s)
-                host_free[s] = torch.cuda.Event(); host_free[s].record(copy_s)
+                if direct is None:
+                    host_free[s] = torch.cuda.Event(); host_free[s].record(copy_s)
+                if ci == len(bounds) - 1:
+                    h2d_ev[1].record(copy_s)
+            h2d_bytes += (hi - lo) * 2
 
-        for s in range(2):
-            free[s].record(comp_s)
-        stage(0)
-        for ci, (a, b) in enumerate(bounds):
-            s = ci & 1
-            if ci + 1 < len(bounds):
-                stage(ci + 1)
-            comp_s.wait_event(ready[s])
-            ms = int(np.max(np.diff(offsets[a:b + 1]))) if b > a else 0
-            res = self.ex.extract_batch_device(dpcm[s], doff[s][: b - a + 1], ms, pooled=True, frames=False)
-            pooled[a:b].copy_(res["pooled"], non_blocking=True)
-            status[a:b].copy_(res["status"], non_blocking=True)
-            free[s].record(comp_s)
-        torch.cuda.synchronize(dev)
-        if pool is not None:
-            pool.shutdown()
+        try:
+            for s in range(2):
+                free[s].record(comp_s)
+            stage(0)
+            for ci, (a, b) in enumerate(bounds):
+                s = ci & 1
+                if ci + 1 < len(bounds):
+                    stage(ci + 1)
+                comp_s.wait_event(ready[s])
+                ms = int(np.max(np.diff(offsets[a:b + 1]))) if b > a else 0
+                res = self.ex.extract_batch_device(dpcm[s], doff[s][: b - a + 1], ms, pooled=True, frames=False)
+                pooled[a:b].copy_(res["pooled"], non_blocking=True)
+                status[a:b].copy_(res["status"], non_blocking=True)
+                free[s].record(comp_s)
+            torch.cuda.synchronize(dev)
+            self.h2d_gbs = h2d_bytes / (h2d_ev[0].elapsed_time(h2d_ev[1]) * 1e-3) / 1e9 if len(bounds) > 1 else None
+        finally:
+            if registered:
+                torch.cuda.synchronize(dev)
+                torch.cuda.cudart().cudaHostUnregister(pcm.ctypes.data)
+            if pool is not None:
+                pool.shutdown()
         return {"pooled": pooled.numpy(), "status": status.numpy()}
