@@ -57,7 +57,7 @@ struct DysfHandle {
   int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   // workspace / staging
-  DevBuf ws_rich, ws_S, ws_stat, ws_flat, ws_energy, ws_hf;
+  DevBuf ws_rich, ws_S, ws_stat, ws_flat, ws_energy, ws_hf, ws_rowmax;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
@@ -154,7 +154,7 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
     (void)hipFree(h->d_window64); (void)hipFree(h->d_window64_i16); (void)hipFree(h->d_stage_tw64); (void)hipFree(h->d_post_tw64);
-    h->ws_S.release(); h->ws_stat.release(); h->ws_flat.release(); h->ws_energy.release(); h->ws_hf.release();
+    h->ws_S.release(); h->ws_stat.release(); h->ws_flat.release(); h->ws_energy.release(); h->ws_hf.release(); h->ws_rowmax.release();
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
@@ -300,6 +300,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.dct_pack32 = h->dct64 ? nullptr : h->d_dct_pack32; a.dct_rowsum = h->d_dct_rowsum; a.inv_n_mels = 1.0f / (float)p.n_mels;
   a.chroma_pack = h->d_chroma_pack; a.chroma_groups = t.chroma_groups;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
+  a.cand_cap = std::max(4096, 16 * ((t.pip_kmax - t.pip_kmin) / 2 + 2));   // 64 KB of LDS, or one round (16 frames) if that is more
 
   // ---- kernel A geometry: small workgroups, several per CU
   const int nt_a = stft_threads(t.NC), nw_a = nt_a / 64;
@@ -321,16 +322,15 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.mel_sched = (const int*)h->d_mel_sched.p;
   a.mel_pack = (const float*)h->d_mel_spack.p;
   a.mel_slots = h->mel_slots;
-  a.tiles_per_wg = 4;
+  a.tiles_per_wg = p.parity ? 12 : 4;   // the parity kernels copy 40-60 KB of float64 tables per workgroup: amortise them
   if (const char* e = std::getenv("DYSF_TILES")) { if (std::atoi(e) > 0) a.tiles_per_wg = std::atoi(e); }
   a.lm_stride = t.mpad;
   a.ws_logmel_stride = t_max * (int64_t)t.mpad;
-  a.peak_tile_cap = p.chroma ? fpi_a * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   a.ws_peak_stride = p.chroma ? t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
   const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * t.L + 3) & ~3;
-  const int tables_a = p.parity ? 0 : tables;  // the float64 tables of the parity presets are read from L2
+  const int tables_a = p.parity ? ((stft_exact_table_floats(p.n_fft) + 3) & ~3) : tables;
   const int tile_a = ((fpi_a - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
-  const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 2 * a.peak_tile_cap + 3) & ~3;
+  const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 3) & ~3;
   const int lds_a_region = 0, lds_a_pcm = nw_a * rstride, lds_a_misc = lds_a_pcm + tile_a, lds_a_tables = lds_a_misc + misc_a;
   size_t lds_a = (size_t)(lds_a_tables + tables_a) * 4;
   if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
@@ -363,7 +363,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const long long hf_M = d_metrics ? hf_ratio_fft_size(max_samples) : 0;
   a.energy_stride = d_metrics ? std::max<int64_t>(1, max_samples >= snr_fl ? 1 + (max_samples - snr_fl) / std::max(1, snr_hop) : 1) : 0;
   const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4 +
-                          (size_t)a.ws_S_stride * 4 + (size_t)a.stat_stride * 3 * p.n_mfcc * 4 +
+                          (size_t)a.ws_S_stride * 4 + (p.chroma ? (size_t)t_max * 4 : 0) + (size_t)a.stat_stride * 3 * p.n_mfcc * 4 +
                           (d_metrics ? (size_t)(t_max + a.energy_stride) * 4 + hf_ratio_bytes_per_clip(hf_M) : 0);
   // a sub-batch is gridDim.y of kernel A: at most 65535 clips
   const int64_t sub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_clips, 65535), (int64_t)(h->ws_budget / per_clip)));
@@ -375,7 +375,11 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     if (int rc = h->ws_peak_bin.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
   }
   if (p.rich) { if (int rc = h->ws_rich.reserve((size_t)sub * a.ws_rich_stride * 14 * 4)) return rc; }
-  if (p.chroma) { if (int rc = h->ws_S.reserve((size_t)sub * a.ws_S_stride * 4)) return rc; }
+  if (p.chroma) {
+    if (int rc = h->ws_S.reserve((size_t)sub * a.ws_S_stride * 4)) return rc;
+    if (int rc = h->ws_rowmax.reserve((size_t)sub * t_max * 4)) return rc;
+  }
+  a.ws_rowmax = p.chroma ? (float*)h->ws_rowmax.p : nullptr;
   if (need_stat) { if (int rc = h->ws_stat.reserve((size_t)sub * a.stat_stride * 3 * p.n_mfcc * 4)) return rc; }
   if (d_metrics) {
     if (int rc = h->ws_flat.reserve((size_t)sub * t_max * 4)) return rc;
@@ -426,7 +430,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
       HIPCHK(launch_metrics(a, dim3(nc), stream));
       HIPCHK(launch_hf_ratio(a, nc, hf_M, h->ws_hf.p, stream));
     }
-    if (p.chroma) HIPCHK(launch_chroma(a, dim3(nc), stream));
+    if (p.chroma) HIPCHK(launch_chroma(a, p.n_fft, dim3(nc), stream));
     if (p.rich) {
       a.rstride = rstride_c;
       a.lds_region = 0; a.lds_pcm = lds_c_pcm; a.lds_misc = lds_c_misc; a.lds_tables = lds_c_tables;

@@ -164,16 +164,12 @@ DYSF_HD void dft16(C* z) {
     }
 }
 
-// One Stockham stage on a lane's 16 points.  Point p = b + NB*r belongs to butterfly b (NB = 16/R
-// butterflies per lane), input slot r.  tw[p] is the stage twiddle (ignored for stage 0).
+// The butterflies of one Stockham stage on a lane's 16 points.  Point p = b + NB*r belongs to butterfly b (NB = 16/R
+// butterflies per lane), input slot r.
 template <int NC, int S, class C>
-DYSF_HD void fft_stage(C* z, const C* tw) {
+DYSF_HD void fft_butterflies(C* z) {
   constexpr int R = FftGeom<NC>::radix(S);
   constexpr int NB = kPts / R;
-  if (S > 0) {
-#pragma unroll
-    for (int p = NB; p < kPts; ++p) z[p] = cmul(z[p], tw[p]);
-  }
   if (R == 16) {
     dft16(z);
   } else if (R == 4) {
@@ -183,6 +179,18 @@ DYSF_HD void fft_stage(C* z, const C* tw) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) dft2<NB>(z + b);
   }
+}
+
+// One Stockham stage: twiddles tw[p] on the points p >= NB (ignored for stage 0), then the butterflies.
+template <int NC, int S, class C>
+DYSF_HD void fft_stage(C* z, const C* tw) {
+  constexpr int R = FftGeom<NC>::radix(S);
+  constexpr int NB = kPts / R;
+  if (S > 0) {
+#pragma unroll
+    for (int p = NB; p < kPts; ++p) z[p] = cmul(z[p], tw[p]);
+  }
+  fft_butterflies<NC, S>(z);
 }
 
 // where stage S stores point p of lane ls (natural order after the last stage)

@@ -58,6 +58,7 @@ struct KArgs {
   float* ws_rich;           // [clip][14][ws_rich_stride] per-frame peak (7 rows) and valley (7 rows) magnitudes
   long long ws_rich_stride;
   int pip_kmin, pip_kmax;
+  int cand_cap;             // kernel C: local maxima its LDS list holds (>= one round's worst case)
   // per-clip global workspace
   float* ws_logmel;            // [clip][T_max][lm_stride] log-mel (dB, un-clamped), frame-major
   long long ws_logmel_stride;  // floats per clip
@@ -66,6 +67,7 @@ struct KArgs {
   float* ws_S;                 // chroma presets: [clip][T_max][s_stride] power spectrogram (kernel A -> kernel C)
   long long ws_S_stride;       // floats per clip
   int s_stride;                // floats per spectrum row = n_bins rounded up to 16 (padding columns are zero)
+  float* ws_rowmax;            // chroma presets: [clip][t_max] largest power-spectrum bin of every frame (piptrack's threshold)
   float* ws_flat;              // metrics launches: [clip][t_max] spectral flatness of every frame (kernel A -> metrics kernel)
   float* ws_energy;            // metrics launches: [clip][energy_stride] 25 ms frame energies of snr_db
   long long energy_stride;
@@ -78,7 +80,6 @@ struct KArgs {
   float* ws_peak_mag;
   int* ws_peak_bin;
   long long ws_peak_stride;    // peak capacity per clip
-  int peak_tile_cap;           // peak capacity of one tile (LDS staging in kernel A)
   // LDS carve-up (float offsets) of the kernel being launched
   int lds_region, lds_pcm, lds_misc, lds_tables;
 };
@@ -99,8 +100,9 @@ constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
-hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s);
+hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s);
 hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s);
+int stft_exact_table_floats(int n_fft);  // LDS floats of the parity presets' float64 FFT tables
 // high_freq_energy_ratio (dysf_hfratio.hip): chirp-z transform of every whole clip on FFTs of size M
 long long hf_ratio_fft_size(long long max_samples);
 size_t hf_ratio_bytes_per_clip(long long M);

@@ -305,36 +305,85 @@ __device__ __forceinline__ float cabs2_numpy(float re, float im) {
   return mul_rn(m, m);
 }
 
+// float64 tables of the parity presets, copied into LDS once per workgroup (read from L2 for every frame they cost
+// 57 KB per 2048-point frame -- 5.5 GB per 1024-clip launch, which bound the first version of this path).
+// Twiddles of a stage are stored as [q][lane] with q counting the points that carry one; a radix-4 stage keeps only its
+// NB base twiddles per lane (exponent r = 1) and squares / cubes them in registers (r = 2, 3).
+template <int NC, int S>
+constexpr int tw64_entries() {   // complex doubles per lane the LDS copy of stage S holds
+  return FftGeom<NC>::radix(S) == 4 ? kPts / 4 : kPts - kPts / FftGeom<NC>::radix(S);
+}
+template <int NC>
+constexpr int fft_tabs64_floats() {
+  return 4 * NC + 2 * (NC + 2) + 4 * FftGeom<NC>::L * (tw64_entries<NC, 1>() + (FftGeom<NC>::NSTAGE == 3 ? tw64_entries<NC, 2>() : 0));
+}
+struct FftTabs64 {
+  const cd* win;   // [NC] (w[2n], w[2n+1]), pre-scaled by 1/2 (and 2^-15 for int16 PCM)
+  const cd* ptw;   // [NC/2+1] un-packing twiddles
+  const cd* t1;    // [q][L] stage-1 twiddles
+  const cd* t2;    // [q][L] stage-2 twiddles (three-stage sizes)
+};
+template <int NC, int NT>
+__device__ __forceinline__ void load_fft_tabs64(float* dst, const KArgs& a, FftTabs64& t) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L;
+  cd* win = (cd*)dst;
+  cd* ptw = win + NC;
+  cd* t1 = ptw + (NC / 2 + 1);
+  cd* t2 = t1 + L * tw64_entries<NC, 1>();
+  for (int i = threadIdx.x; i < NC; i += NT) win[i] = ((const cd*)a.window64)[i];
+  for (int i = threadIdx.x; i < NC / 2 + 1; i += NT) ptw[i] = ((const cd*)a.post_tw64)[i];
+  constexpr int NB1 = kPts / G::radix(1);
+  for (int i = threadIdx.x; i < L * tw64_entries<NC, 1>(); i += NT)
+    t1[i] = ((const cd*)a.stage_tw64)[(i % L) * kPts + NB1 + i / L];
+  if (G::NSTAGE == 3) {
+    constexpr int NB2 = kPts / G::radix(2);
+    for (int i = threadIdx.x; i < L * tw64_entries<NC, 2>(); i += NT)
+      t2[i] = ((const cd*)a.stage_tw64)[(size_t)L * kPts + (i % L) * kPts + NB2 + i / L];
+  }
+  t.win = win; t.ptw = ptw; t.t1 = t1; t.t2 = t2;
+}
+
+// twiddles of stage S from the LDS copy, then the butterflies
+template <int NC, int S>
+__device__ __forceinline__ void fft_stage64(cd* z, const cd* tw, int ls) {
+  using G = FftGeom<NC>;
+  constexpr int L = G::L, R = G::radix(S), NB = kPts / R;
+  if (R == 4) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const cd w1 = tw[b * L + ls];
+      const cd w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+      z[b + NB] = cmul(z[b + NB], w1);
+      z[b + 2 * NB] = cmul(z[b + 2 * NB], w2);
+      z[b + 3 * NB] = cmul(z[b + 3 * NB], w3);
+    }
+  } else {
+#pragma unroll
+    for (int p = NB; p < kPts; ++p) z[p] = cmul(z[p], tw[(p - NB) * L + ls]);
+  }
+  fft_butterflies<NC, S>(z);
+}
+
 template <int NC>
 __device__ __forceinline__ void wave_frame_power_exact(const float* tile, int frame_off, double* xb, float* srow,
-                                                       int ls, const KArgs& a) {
+                                                       int ls, const FftTabs64& tb, const KArgs& a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L;
   constexpr int LAST = G::NSTAGE - 1;
-  const cd* win = (const cd*)a.window64;
   cd z[kPts];
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
     const int n = ls + L * p;
     const cd x = {(double)tile[frame_off + 2 * n], (double)tile[frame_off + 2 * n + 1]};
-    z[p] = x * win[n];  // one float64 rounding per sample, as numpy's float64(frame) * window
+    z[p] = x * tb.win[n];  // one float64 rounding per sample, as numpy's float64(frame) * window
   }
-  fft_stage<NC, 0>(z, (const cd*)nullptr);
+  fft_butterflies<NC, 0>(z);
   fft_exchange64<NC, 0>(z, xb, ls);
-  {
-    cd t1[kPts];
-    const cd* tw = (const cd*)a.stage_tw64 + ls * kPts;
-#pragma unroll
-    for (int p = 0; p < kPts; ++p) t1[p] = tw[p];
-    fft_stage<NC, 1>(z, t1);
-  }
+  fft_stage64<NC, 1>(z, tb.t1, ls);
   if (G::NSTAGE == 3) {
     fft_exchange64<NC, 1>(z, xb, ls);
-    cd t2[kPts];
-    const cd* tw = (const cd*)a.stage_tw64 + (size_t)L * kPts + ls * kPts;
-#pragma unroll
-    for (int p = 0; p < kPts; ++p) t2[p] = tw[p];
-    fft_stage<NC, 2>(z, t2);
+    fft_stage64<NC, 2>(z, tb.t2, ls);
   }
   cd zk[9], zm[9];
 #pragma unroll
@@ -359,7 +408,7 @@ __device__ __forceinline__ void wave_frame_power_exact(const float* tile, int fr
   for (int i = 0; i < 9; ++i) {
     const int k = (i == 8) ? NC / 2 : ls + L * i;
     cd xk, xm;
-    rfft_pair(zk[i], zm[i], ((const cd*)a.post_tw64)[k], &xk, &xm);
+    rfft_pair(zk[i], zm[i], tb.ptw[k], &xk, &xm);
     if (i < 8 || ls == 0) {
       srow[k] = cabs2_numpy((float)xk[0], (float)xk[1]);       // complex64 rounding, then |.|**2 in float32
       srow[NC - k] = cabs2_numpy((float)xm[0], (float)xm[1]);
@@ -369,71 +418,30 @@ __device__ __forceinline__ void wave_frame_power_exact(const float* tile, int fr
 }
 
 // ---------------------------------------------------------------------------------------------
-// piptrack on one power-spectrum row (the wave's own frame): append (mag, histogram bin) of every
-// local maximum above 0.1*max in [pip_kmin, pip_kmax) to the workgroup's peak list.
+// piptrack, second half: one local maximum (bin k, power x0, neighbours xm / x1) -> interpolated magnitude and the
+// histogram bin of its pitch residual.  Follows librosa.piptrack / pitch_tuning step by step (numba promotes the integer
+// literals of the parabolic interpolation to float64; the residual is float32; np.histogram's edges are i * 0.01 - 0.5 in
+// float64 with a closed last bin).
 template <int NC>
-__device__ __forceinline__ void frame_peaks(const float* srow, int ls, bool frame_valid, const KArgs& a,
-                                            float* peak_mag /*LDS*/, int* peak_bin /*LDS*/, int* peak_count /*LDS*/,
-                                            int peak_cap) {
-  constexpr int L = FftGeom<NC>::L;
-  float mx = 0.f;
-  for (int k = ls; k <= NC; k += L) mx = fmaxf(mx, srow[k]);
-#pragma unroll
-  for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  const float ref = mul_rn(0.1f, mx);
-  const int lane = threadIdx.x & 63;
-  const int span = a.pip_kmax - a.pip_kmin;
-  // Peaks are sparse (a few per 64 bins) and the interpolation below is float64-heavy, so a lane parks its candidate
-  // and the heavy block runs only when some lane finds a second one (or at the end): ~3 dense runs per frame instead
-  // of one sparse run per 64-bin pass.  The order of the list entries changes; median and histogram do not care.
-  bool pend = false;
-  int pk = 0;
-  float px0 = 0.f, pxm = 0.f, px1 = 0.f;
-  auto flush = [&]() {
-    const unsigned long long mask = __ballot(pend);
-    if (mask == 0ull) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(peak_count, __popcll(mask));
-    base = __shfl(base, 0);
-    if (pend) {
-      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-      const int k = pk;
-      const float x0 = px0, xm = pxm, x1 = px1;
-      // numba-typed parabolic interpolation of librosa.piptrack (int literals promote to float64)
-      const float dsum = add_rn(x1, xm), ddif = sub_rn(x1, xm);
-      const double pa = (double)dsum - 2.0 * (double)x0;
-      const double pb = (double)ddif / 2.0;
-      const float shift = (fabs(pb) >= fabs(pa)) ? 0.f : (float)(-pb / pa);
-      const float avg = mul_rn(ddif, 0.5f);
-      const float mag = add_rn(x0, mul_rn(mul_rn(0.5f, avg), shift));
-      const float pitch = (float)((((double)k + (double)shift) * (double)a.sr) / (double)(2 * NC));
-      // pitch_tuning residual, float32 like numpy; log2 is correctly rounded via float64
-      const float octs = (float)log2((double)div_rn(pitch, 27.5f));
-      const float x12 = mul_rn(12.0f, octs);
-      float r = x12 - floorf(x12);
-      if (r >= 0.5f) r = sub_rn(r, 1.0f);
-      const double rd = (double)r;
-      int b = (int)floor((rd + 0.5) * 100.0);
-      b = b < 0 ? 0 : (b > 99 ? 99 : b);
-      while (b > 0 && rd < dadd_rn(dmul_rn((double)b, 0.01), -0.5)) --b;
-      while (b < 99 && rd >= dadd_rn(dmul_rn((double)(b + 1), 0.01), -0.5)) ++b;
-      if (slot < peak_cap) { peak_mag[slot] = mag; peak_bin[slot] = b; }
-    }
-    pend = false;
-  };
-  for (int kk = 0; kk < span; kk += L) {  // uniform trip count across the wave
-    const int k = a.pip_kmin + kk + ls;
-    bool is_peak = false;
-    float x0 = 0.f, xm = 0.f, x1 = 0.f;
-    if (frame_valid && k < a.pip_kmax) {
-      x0 = srow[k]; xm = srow[k - 1]; x1 = srow[k + 1];
-      const float z0 = x0 > ref ? x0 : 0.f, zm = xm > ref ? xm : 0.f, z1 = x1 > ref ? x1 : 0.f;
-      is_peak = (z0 > zm) && (z0 >= z1);
-    }
-    if (__ballot(is_peak && pend) != 0ull) flush();  // some lane would overwrite its parked candidate
-    if (is_peak) { pend = true; pk = k; px0 = x0; pxm = xm; px1 = x1; }
-  }
-  flush();
+__device__ __forceinline__ void peak_to_mag_bin(int k, float x0, float xm, float x1, const KArgs& a, float* mag_out, int* bin_out) {
+  const float dsum = add_rn(x1, xm), ddif = sub_rn(x1, xm);
+  const double pa = (double)dsum - 2.0 * (double)x0;
+  const double pb = (double)ddif / 2.0;
+  const float shift = (fabs(pb) >= fabs(pa)) ? 0.f : (float)(-pb / pa);
+  const float avg = mul_rn(ddif, 0.5f);
+  *mag_out = add_rn(x0, mul_rn(mul_rn(0.5f, avg), shift));
+  const float pitch = (float)((((double)k + (double)shift) * (double)a.sr) / (double)(2 * NC));
+  // pitch_tuning residual, float32 like numpy; log2 is correctly rounded via float64
+  const float octs = (float)log2((double)div_rn(pitch, 27.5f));
+  const float x12 = mul_rn(12.0f, octs);
+  float r = x12 - floorf(x12);
+  if (r >= 0.5f) r = sub_rn(r, 1.0f);
+  const double rd = (double)r;
+  int b = (int)floor((rd + 0.5) * 100.0);
+  b = b < 0 ? 0 : (b > 99 ? 99 : b);
+  while (b > 0 && rd < dadd_rn(dmul_rn((double)b, 0.01), -0.5)) --b;
+  while (b < 99 && rd >= dadd_rn(dmul_rn((double)(b + 1), 0.01), -0.5)) ++b;
+  *bin_out = b;
 }
 
 // r-th smallest (0-based) of the n positive floats in v (bit order = numeric order), by most-significant-byte-first
@@ -585,16 +593,15 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
   double* xb64 = (double*)wregion + q * G::XSTRIDE;  // EX: the exchange buffer holds doubles (rstride is sized for it)
   float* srow_own = wregion + q * a.kpad;
   FftTabs tb;
-  if (!EX) load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);  // EX reads its float64 tables from L2
+  FftTabs64 tb64;
+  if (EX) load_fft_tabs64<NC, NT>(lds + a.lds_tables, a, tb64);
+  else load_fft_tabs<NC, NT, PCM>(lds + a.lds_tables, a, tb);
   // the mel product reads a few words past a spectrum row's last bin (see mel_segment): no stale LDS there
   for (int i = tid * 4; i < NW * a.rstride; i += NT * 4) *(float4*)(regions + i) = float4{0.f, 0.f, 0.f, 0.f};
   int* sched = imisc + 32;
   for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
   const int* wsched = sched + wave * kMelSchedStride;
   float* slots = misc + 32 + 8 * kMelSchedStride;
-  float* pk_mag = slots + a.mel_slots * 256;            // chroma only: this tile's peaks
-  int* pk_bin = (int*)(pk_mag + a.peak_tile_cap);
-  if (tid == 0) imisc[16] = 0;
   f32x4 pend = {0.f, 0.f, 0.f, 0.f};
   float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
 
@@ -626,11 +633,18 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
     }
     {
       const int fl = wave * FPW + q;  // frame within tile
-      if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, a);
+      if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, tb64, a);
       else wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
       STAMP(1);  // prefetch issue + FFT
-      if (CH && a.chroma) frame_peaks<NC>(srow_own, ls, (f0 + fl) < T, a, pk_mag, pk_bin, &imisc[16], a.peak_tile_cap);
-      STAMP(7);  // piptrack
+      if (CH && a.ws_rowmax) {  // piptrack's threshold is 0.1 * the frame's largest bin: kernel C picks the peaks from the stored rows
+        float mx = 0.f;
+        for (int k = lane % L; k <= NC; k += L) mx = fmaxf(mx, srow_own[k]);
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int t = f0 + wave * FPW + q;
+        if (lane % L == 0 && t < T) a.ws_rowmax[(size_t)clip * a.t_max + t] = mx;
+      }
+      STAMP(7);  // row maximum
       if (CH && a.ws_flat) {
         // librosa.feature.spectral_flatness of this frame (pipeline1.py:168-174): geometric over arithmetic mean of
         // max(1e-10, |D|**2) across the bins
@@ -666,19 +680,6 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
         const int f = i / (NC + 1), k = i % (NC + 1);
         if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[(f / FPW) * a.rstride + (f % FPW) * a.kpad + k];
       }
-    }
-    if (CH && a.chroma) {  // flush this tile's peaks to the clip's list: one global atomic per tile
-      int* gcnt = a.ws_peak_cnt + clip;
-      const int cnt = min(imisc[16], a.peak_tile_cap);
-      __shared__ int gbase;
-      if (tid == 0) gbase = atomicAdd(gcnt, cnt);
-      __syncthreads();
-      float* gm = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
-      int* gb = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
-      for (int i = tid; i < cnt; i += NT)
-        if (gbase + i < a.ws_peak_stride) { gm[gbase + i] = pk_mag[i]; gb[gbase + i] = pk_bin[i]; }
-      __syncthreads();
-      if (tid == 0) imisc[16] = 0;
     }
     // banded mel GEMM on MFMA: D[16 mels x 16 frames] += Wpack[16 x 4] * S[4 x 16], following this wave's
     // slice of the host-built schedule (row blocks with long bands are split along K over several waves)
@@ -1091,9 +1092,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
 // streams their spectrum rows straight from HBM into MFMA B operands (16 bytes per lane, eight loads in flight):
 // K is walked in groups of 16 bins, lane (frame = l & 15, q = l >> 4) holding the four consecutive bins 16g + 4q + s,
 // and the bank pack has the same order ([tuning][group][lane][4]), so there is no LDS staging and no second FFT.
-template <int NT>
+template <int NC, int NT>
 __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
+  extern __shared__ __align__(16) float4 sm_cand[];   // [2 * NW frames][(pip_kmax - pip_kmin) / 2 + 2] parked local maxima (they cannot be adjacent)
+  __shared__ int sm_cnt;
   __shared__ int sm_i[400];                    // [0..1] select control, [16..115] tuning histogram, [128..383] radix histogram
   __shared__ double sm_red[NW * kChroma * 2];  // per-wave partial sums of the chroma rows
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1107,10 +1110,88 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     if (tid == 0 && a.tuning) a.tuning[clip] = 50;
     return;
   }
-  const float* pk_mag = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
-  const int* pk_bin = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
+  float* pk_mag = a.ws_peak_mag + (size_t)clip * a.ws_peak_stride;
+  int* pk_bin = a.ws_peak_bin + (size_t)clip * a.ws_peak_stride;
   int* hist = sm_i + 16;
-  int npk = a.ws_peak_cnt[clip];
+  const float* S = a.ws_S + (size_t)clip * a.ws_S_stride;
+  // ---- librosa.piptrack on the stored power spectrogram: a wave takes a frame per round; local maxima above 0.1 * the
+  // frame's largest bin inside [pip_kmin, pip_kmax) are parked in LDS (bin, power, neighbours), then converted densely --
+  // one thread per peak -- to (interpolated magnitude, histogram bin) and appended to the clip's list in the workspace.
+  int npk = 0;
+  {
+    // Two frames per wave and round; a lane owns four consecutive bins of every 256-bin slice of its frame's row (one
+    // 16-byte load per slice, all slices of both frames requested before the first is looked at), the neighbours of
+    // its first and last bin come from the adjacent lanes.
+    constexpr int NV = (NC + 1 + 255) / 256;       // 256-bin slices that cover bins 0 .. NC
+    constexpr int FPR = 2;                         // frames per wave per round
+    const float* rowmax = a.ws_rowmax + (size_t)clip * a.t_max;
+    const int nv = min(NV, (a.pip_kmax + 1 + 255) / 256);   // slices that reach the pitch band (wave-uniform)
+    const int per_round = NW * FPR * ((a.pip_kmax - a.pip_kmin) / 2 + 2);   // most local maxima one round can park
+    if (tid == 0) sm_cnt = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += NW * FPR) {
+      float4 v[FPR][NV];
+      float ref[FPR];
+#pragma unroll
+      for (int f = 0; f < FPR; ++f) {
+        const int t = t0 + wave + f * NW;
+        const float* row = S + (size_t)(t < T ? t : T - 1) * a.s_stride + 4 * lane;
+        ref[f] = mul_rn(0.1f, rowmax[t < T ? t : T - 1]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (i < nv) v[f][i] = (256 * i + 4 * lane + 3 < a.s_stride) ? *(const float4*)(row + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int f = 0; f < FPR; ++f) {
+        const int t = t0 + wave + f * NW;
+        if (t >= T) continue;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          if (i >= nv) continue;
+          const float4 c = v[f][i];
+          // left neighbour of .x: lane - 1's .w (lane 0: the previous slice's lane 63); right neighbour of .w: lane + 1's .x
+          float left = __shfl_up(c.w, 1), right = __shfl_down(c.x, 1);
+          if (lane == 0) left = 0.f;
+          if (i > 0) { const float pw = __shfl(v[f][i - 1].w, 63); if (lane == 0) left = pw; }
+          float nx = 0.f;
+          if (i + 1 < NV && i + 1 < nv) nx = __shfl(v[f][i + 1].x, 0);
+          else if (lane == 63) nx = 0.f;
+          if (lane == 63) right = nx;
+          const float xs[6] = {left, c.x, c.y, c.z, c.w, right};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = 256 * i + 4 * lane + j;
+            const float x0 = xs[j + 1], xm = xs[j], x1 = xs[j + 2];
+            const float z0 = x0 > ref[f] ? x0 : 0.f, zm = xm > ref[f] ? xm : 0.f, z1 = x1 > ref[f] ? x1 : 0.f;
+            const bool is_peak = (k >= a.pip_kmin) && (k < a.pip_kmax) && (z0 > zm) && (z0 >= z1);
+            const unsigned long long mask = __ballot(is_peak);
+            if (mask != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&sm_cnt, __popcll(mask));
+              base = __shfl(base, 0);
+              if (is_peak) sm_cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(__int_as_float(k), x0, xm, x1);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int cnt = sm_cnt;
+      // convert and flush only when the next round might not fit (typical clips: once, at the end)
+      if (cnt + per_round > a.cand_cap || t0 + NW * FPR >= T) {
+        for (int i = tid; i < cnt; i += NT) {
+          const float4 c = sm_cand[i];
+          float mag; int bin;
+          peak_to_mag_bin<NC>(__float_as_int(c.x), c.y, c.z, c.w, a, &mag, &bin);
+          if (npk + i < (int)a.ws_peak_stride) { pk_mag[npk + i] = mag; pk_bin[npk + i] = bin; }
+        }
+        npk += cnt;
+        __syncthreads();
+        if (tid == 0) sm_cnt = 0;
+        __syncthreads();
+      }
+    }
+    if (tid == 0) a.ws_peak_cnt[clip] = npk;   // (dysf_debug_peaks)
+  }
   npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
   int tune = 50;
   if (npk > 0) {
@@ -1136,7 +1217,6 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   if (!a.pooled) return;
 
   const float* bank = a.chroma_pack + (size_t)tune * a.chroma_groups * 256 + lane * 4;
-  const float* S = a.ws_S + (size_t)clip * a.ws_S_stride;
   const int ncb = (T + 15) / 16;
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   for (int cb = wave; cb < ncb; cb += NW) {
@@ -1536,13 +1616,29 @@ hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t 
   if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
   return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);
 }
+int stft_exact_table_floats(int n_fft) {
+  switch (n_fft) {
+    case 256: return fft_tabs64_floats<128>();
+    case 512: return fft_tabs64_floats<256>();
+    case 1024: return fft_tabs64_floats<512>();
+    default: return fft_tabs64_floats<1024>();
+  }
+}
+
 hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL(dysf_metrics_kernel<256>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_chroma(const KArgs& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(dysf_chroma_kernel<512>, grid, dim3(512), 0, s, a);
+hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s) {
+  const size_t lds = (size_t)a.cand_cap * sizeof(float4);   // <= 64 KB: no attribute needed
+  switch (n_fft) {
+    case 256: hipLaunchKernelGGL((dysf_chroma_kernel<128, 512>), grid, dim3(512), lds, s, a); break;
+    case 512: hipLaunchKernelGGL((dysf_chroma_kernel<256, 512>), grid, dim3(512), lds, s, a); break;
+    case 1024: hipLaunchKernelGGL((dysf_chroma_kernel<512, 512>), grid, dim3(512), lds, s, a); break;
+    case 2048: hipLaunchKernelGGL((dysf_chroma_kernel<1024, 512>), grid, dim3(512), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
