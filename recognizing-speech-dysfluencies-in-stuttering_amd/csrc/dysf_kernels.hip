@@ -295,13 +295,37 @@ __device__ __forceinline__ void fft_exchange64(cd* z, double* xb, int ls) {
   }
 }
 
+// Correctly rounded a / b for 0 <= a <= b, b in [2^-60, 2^60], and correctly rounded sqrt(x) for x in [1, 2]: the
+// reciprocal / reciprocal-square-root instruction plus fma corrections, without the scaling and fix-up steps of the
+// general library sequences (half their instructions).  tools/checks/rn_check.hip compares them on the GPU with the
+// correctly rounded operators: sqrt over all 2^23 + 1 floats of [1, 2], division over 2^28 random pairs, no mismatch.
+__device__ __forceinline__ float div_rn_unit(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  const float q = mul_rn(a, r);
+  const float rem = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(rem, r, q);
+}
+__device__ __forceinline__ float sqrt_rn_12(float x) {
+  const float s = __builtin_amdgcn_rsqf(x);
+  float g = mul_rn(x, s), h = mul_rn(0.5f, s);
+  const float r = __builtin_fmaf(-h, g, 0.5f);
+  g = __builtin_fmaf(g, r, g);
+  h = __builtin_fmaf(h, r, h);
+  const float d = __builtin_fmaf(-g, g, x);
+  return __builtin_fmaf(d, h, g);
+}
+
 // np.abs of one complex64 value as NumPy's SIMD loop computes it (loops_unary_complex.dispatch.c.src, FMA form):
 // larger * sqrt(fma(r, r, 1)) with r = smaller / larger, every step rounded to float32; then squared.
 __device__ __forceinline__ float cabs2_numpy(float re, float im) {
   const float ar = fabsf(re), ai = fabsf(im);
   const float lg = fmaxf(ar, ai), sm = fminf(ai, ar);
-  const float ratio = (lg > 0.f && lg < INFINITY) ? div_rn(sm, lg) : 0.f;
-  const float m = mul_rn(sqrt_rn(__builtin_fmaf(ratio, ratio, 1.0f)), lg);
+  float ratio;
+  if (lg > 8.7e-19f && lg < 1.1e18f) ratio = div_rn_unit(sm, lg);            // every bin that can matter
+  else ratio = (lg > 0.f && lg < INFINITY) ? div_rn(sm, lg) : 0.f;
+  const float m = mul_rn(sqrt_rn_12(__builtin_fmaf(ratio, ratio, 1.0f)), lg);
   return mul_rn(m, m);
 }
 
@@ -365,9 +389,11 @@ __device__ __forceinline__ void fft_stage64(cd* z, const cd* tw, int ls) {
   fft_butterflies<NC, S>(z);
 }
 
+// grow: this frame's row in the spectrogram workspace (null: not kept); returns the frame's largest bin in every lane of
+// the frame's lane group (piptrack's threshold) -- both come straight from the registers that hold the new bins.
 template <int NC>
-__device__ __forceinline__ void wave_frame_power_exact(const float* tile, int frame_off, double* xb, float* srow,
-                                                       int ls, const FftTabs64& tb, const KArgs& a) {
+__device__ __forceinline__ float wave_frame_power_exact(const float* tile, int frame_off, double* xb, float* srow,
+                                                        int ls, const FftTabs64& tb, const KArgs& a, float* grow) {
   using G = FftGeom<NC>;
   constexpr int L = G::L;
   constexpr int LAST = G::NSTAGE - 1;
@@ -404,17 +430,26 @@ __device__ __forceinline__ void wave_frame_power_exact(const float* tile, int fr
   for (int k = NC + 1 + ls; k < a.kpad; k += L) srow[k] = 0.f;
   for (int k = ls; k < 40; k += L) srow[a.kpad + k] = 0.f;  // (the next row's head is rewritten below by its own lanes)
   wave_lds_sync();
+  float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int k = (i == 8) ? NC / 2 : ls + L * i;
     cd xk, xm;
     rfft_pair(zk[i], zm[i], tb.ptw[k], &xk, &xm);
     if (i < 8 || ls == 0) {
-      srow[k] = cabs2_numpy((float)xk[0], (float)xk[1]);       // complex64 rounding, then |.|**2 in float32
-      srow[NC - k] = cabs2_numpy((float)xm[0], (float)xm[1]);
+      const float pk = cabs2_numpy((float)xk[0], (float)xk[1]);       // complex64 rounding, then |.|**2 in float32
+      const float pm = cabs2_numpy((float)xm[0], (float)xm[1]);
+      srow[k] = pk;
+      srow[NC - k] = pm;
+      mx = fmaxf(mx, fmaxf(pk, pm));
+      if (grow) { grow[k] = pk; grow[NC - k] = pm; }   // consecutive lanes, consecutive (or descending) bins: 256-byte segments
     }
   }
+  if (grow) for (int k = NC + 1 + ls; k < a.s_stride; k += L) grow[k] = 0.f;   // padding columns (the chroma GEMM reads them)
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   wave_lds_sync();
+  return mx;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -633,16 +668,19 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
     }
     {
       const int fl = wave * FPW + q;  // frame within tile
-      if (EX) wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, tb64, a);
+      const int t_own = f0 + fl;
+      float* grow = (CH && sdst && t_own < T) ? sdst + (size_t)t_own * a.s_stride : nullptr;
+      float mx_own = 0.f;
+      if (EX) mx_own = wave_frame_power_exact<NC>(tile + cur_shift, fl * a.hop, xb64, srow_own, ls, tb64, a, grow);
       else wave_frame_power<NC>(tile + cur_shift, fl * a.hop, xb, srow_own, ls, tb, a);
       STAMP(1);  // prefetch issue + FFT
       if (CH && a.ws_rowmax) {  // piptrack's threshold is 0.1 * the frame's largest bin: kernel C picks the peaks from the stored rows
-        float mx = 0.f;
-        for (int k = lane % L; k <= NC; k += L) mx = fmaxf(mx, srow_own[k]);
+        if (!EX) {
+          for (int k = lane % L; k <= NC; k += L) mx_own = fmaxf(mx_own, srow_own[k]);
 #pragma unroll
-        for (int o = L / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const int t = f0 + wave * FPW + q;
-        if (lane % L == 0 && t < T) a.ws_rowmax[(size_t)clip * a.t_max + t] = mx;
+          for (int o = L / 2; o > 0; o >>= 1) mx_own = fmaxf(mx_own, __shfl_xor(mx_own, o));
+        }
+        if (lane % L == 0 && t_own < T) a.ws_rowmax[(size_t)clip * a.t_max + t_own] = mx_own;
       }
       STAMP(7);  // row maximum
       if (CH && a.ws_flat) {
@@ -655,11 +693,10 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
         }
 #pragma unroll
         for (int o = L / 2; o > 0; o >>= 1) { slog += __shfl_xor(slog, o); ssum += __shfl_xor(ssum, o); }
-        const int t = f0 + wave * FPW + q;
-        if (lane % L == 0 && t < T)
-          a.ws_flat[(size_t)clip * a.t_max + t] = div_rn(expf(slog / (float)(NC + 1)), ssum / (float)(NC + 1));
+        if (lane % L == 0 && t_own < T)
+          a.ws_flat[(size_t)clip * a.t_max + t_own] = div_rn(expf(slog / (float)(NC + 1)), ssum / (float)(NC + 1));
       }
-      if (CH && sdst) {  // chroma presets keep the power spectrogram for kernel C: the wave's own FPW rows, 256-byte segments
+      if (CH && sdst && !EX) {  // float32-FFT chroma presets: the wave's own FPW rows from LDS, 256-byte segments
 #pragma unroll
         for (int qq = 0; qq < FPW; ++qq) {
           const int t = f0 + wave * FPW + qq;
