@@ -15,6 +15,10 @@ Workloads (BASELINE.json `configs`):
   --config 4         configs[3]: 100 000 clips (clip j = bank clip j mod 1024) sharded contiguously over the ranks
                      (12 500 per GPU at N = 8), resident; pooled rows -> MLP head -> one all-gather of [n_local, 3]; the
                      gathered arg-max is checked against the single-GPU result of the bank.  Strong scaling.
+  --config 5         configs[4]: per GPU 1024 clips of 1-10 s at 22.05 kHz (lengths ~ U[1, 10] s, seed 4321 + rank), 2048-pt STFT
+                     hop 512, 128 mels, 20 MFCC + delta + delta2; the clips are grouped by ceil(seconds) into 10 buckets, each
+                     bucket is one ragged launch padded to its own longest clip (frame rows [n_b, 60, T_b]) followed by the
+                     CNN head in float16 MFMA with the clips' true widths; logits are put back in clip order and all-gathered.
   --preset reference_149   the reference's own parameterisation (2048 / 512 / 128 mels / 20 MFCC + chroma, parity mode)
                      on the same 1024 clips per GPU: pooled 144-d rows + tuning index -> MLP(149 -> 128 -> 64 -> 3).
 
@@ -107,8 +111,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 with --config 4)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
-                    help="2 = BASELINE configs[1] (1024 clips per GPU, weak scaling); 4 = configs[3] (100k clips, strong scaling)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
+                    help="2 = BASELINE configs[1] (1024 clips per GPU, weak scaling); 4 = configs[3] (100k clips, strong scaling); "
+                         "5 = configs[4] (1-10 s clips at 22.05 kHz in 10 length buckets, 128 mels, float16-MFMA CNN head)")
     ap.add_argument("--preset", default="bench_512", choices=("bench_512", "reference_149"))
     ap.add_argument("--head", default="mlp", choices=("mlp", "cnn"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +182,7 @@ def main():
     workers = args.bank_workers or max(1, min(8, len(os.sched_getaffinity(0)) // max(1, world)))
     bank = synth_bank(BATCH, N_SAMPLES, 16000, workers=workers)
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config != 5:
         cpu = cpu_baseline(bank[:256], args.preset)
 
     torch.cuda.set_device(local_rank)
@@ -201,7 +206,30 @@ def main():
         pcm = bank_dev.reshape(-1)
     offsets = (torch.arange(0, n_local + 1, dtype=torch.int64) * N_SAMPLES).to(dev)
 
+    buckets = None
+    if args.config == 5:
+        if args.preset != "bench_512" or args.head != "mlp":
+            raise SystemExit("--config 5 fixes its own parameters (2048 / 512 / 128 mels at 22.05 kHz) and head (CNN, float16 MFMA)")
+        sr5 = 22050
+        rng5 = np.random.default_rng(4321 + rank)
+        lens = (rng5.uniform(1.0, 10.0, size=BATCH) * sr5).astype(np.int64)
+        sec = np.minimum(10, np.ceil(lens / sr5).astype(np.int64))
+        src = torch.from_numpy(bank.reshape(-1)).to(dev)             # 49 M samples of synthetic audio to cut the clips from
+        buckets = []
+        for b in range(1, 11):
+            idx = np.nonzero(sec == b)[0]
+            if len(idx) == 0:
+                continue
+            bl = lens[idx]
+            starts = rng5.integers(0, src.numel() - int(bl.max()), size=len(idx))
+            boff = np.concatenate([[0], np.cumsum(bl)]).astype(np.int64)
+            bpcm = torch.cat([src[int(s0):int(s0) + int(n)] for s0, n in zip(starts, bl)])
+            buckets.append({"idx": torch.from_numpy(idx).to(dev), "pcm": bpcm, "off": torch.from_numpy(boff).to(dev),
+                            "max": int(bl.max()), "n": len(idx), "samples": int(bl.sum())})
+        total_samples5 = int(lens.sum())
     params = rsd_amd.REFERENCE_149 if args.preset == "reference_149" else rsd_amd.BENCH_512
+    if args.config == 5:
+        params = rsd_amd.FeatureParams(sr=22050, chroma=False, parity=False)   # 2048 / 512 / 128 mels / 20 MFCC, librosa defaults
     want_frames = args.preset == "bench_512" and args.config == 2
     ex = rsd_amd.FeatureExtractor(params, local_rank)
     T = params.n_frames(N_SAMPLES)
@@ -211,7 +239,7 @@ def main():
     head_w = [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(3)]
     head_b = [np.zeros(dims[i + 1]) for i in range(3)]
     cnn = None
-    if args.head == "cnn":
+    if args.head == "cnn" or args.config == 5:
         from rsd_amd.classifier import CNNHead, FusedCNNHead
         torch.manual_seed(0)
         cnn = FusedCNNHead(CNNHead().to(dev))
@@ -242,7 +270,28 @@ def main():
         res["logits"] = run_head(res)
         res["all_logits"] = gather_rows(res["logits"], total, rank, world)
 
+    def step5():
+        """configs[4]: one ragged launch + CNN per length bucket, logits scattered back into clip order, one all-gather."""
+        logits = torch.empty((BATCH, 3), dtype=torch.float32, device=dev)
+        status = torch.empty(BATCH, dtype=torch.int32, device=dev)
+        for i, b in enumerate(buckets):
+            k = i % n_lanes
+            with torch.cuda.stream(lanes.streams[k]):
+                r = lanes.extractors[k].extract_batch_device(b["pcm"], b["off"], b["max"], pooled=False, frames=True)
+                cols = ((b["off"][1:] - b["off"][:-1]) // params.hop + 1).to(torch.int32)
+                logits.index_copy_(0, b["idx"], cnn(r["frames"], cols=cols))
+                status.index_copy_(0, b["idx"], r["status"])
+                for t in (logits, status):
+                    t.record_stream(lanes.streams[k])
+        lanes.join()
+        lanes.fork()
+        res = {"logits": logits, "status": status}
+        res["all_logits"] = gather_rows(logits, total, rank, world)
+        return res
+
     def step():
+        if args.config == 5:
+            return step5()
         if args.config == 4:   # one big resident shard: 2048-clip chunks alternate between the lanes, then head + gather
             res = lanes.extract_large(pcm, offsets, N_SAMPLES, chunk_clips=2048, pooled=True, frames=False)
             after(res)
@@ -284,13 +333,27 @@ def main():
         # per-kernel durations: a few extra launches outside the timed region, HIP events inside the library (on the
         # launch stream) around each kernel
         k_pcm, k_off, k_n = (pcm, offsets, n_local) if args.config == 2 else (bank_dev.reshape(-1), offsets[:BATCH + 1], BATCH)
+        cnn_ms = None
+        feat5_ms = cnn5_ms = None
+        if args.config == 5:   # feature launches and CNN launches of all buckets, each timed back to back on one stream
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            frs = []
+            e[0].record()
+            for b in buckets:
+                frs.append(ex.extract_batch_device(b["pcm"], b["off"], b["max"], pooled=False, frames=True)["frames"])
+            e[1].record()
+            for b, fr in zip(buckets, frs):
+                cnn(fr, cols=((b["off"][1:] - b["off"][:-1]) // params.hop + 1).to(torch.int32))
+            e[2].record()
+            torch.cuda.synchronize(dev)
+            feat5_ms, cnn5_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+            del frs
         ex.kernel_timing(True)
         for _ in range(10):
             ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)
             per_kernel.append(ex.kernel_timing(True))
         ex.kernel_timing(False)
-        cnn_ms = None
-        if cnn is not None:
+        if cnn is not None and args.config != 5:
             fr = ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)["frames"]
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             cnn(fr)
@@ -340,7 +403,7 @@ def main():
                                    "h2d_gb_per_s_on_the_copy_stream": round(se.h2d_gbs, 2) if se.h2d_gbs else None, "path": se.describe()}
                 del flat
             host_rate["clips_per_s"] = host_rate["pinned_source"]["clips_per_s"]
-    assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3)
+    assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3), (int(res["status"].abs().sum()), all_logits.shape)
     assert bool(torch.isfinite(all_logits).all())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -380,7 +443,7 @@ def main():
             (2, "reference_149", "mlp"): "the reference's own parameterisation (pipeline1.py:216-228): 1024 clips x 48000 int16 samples per "
                                          "GPU resident in HBM, 2048-pt STFT hop 512, 128 Slaney mels, 20 MFCC + delta + delta2 + chroma_stft "
                                          "(tuning estimate), parity mode (float64 FFT), pooled [1024,144] fp32 -> MLP(149->128->64->3)",
-        }[(args.config, args.preset, args.head)]
+        }.get((args.config, args.preset, args.head), "")
         out = {
             "metric": "clips/sec (3 s@16 kHz, 40-MFCC) end-to-end", "value": round(clips_per_s, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -415,7 +478,7 @@ def main():
         }
         if params.chroma:
             out["roofline"]["kernels"]["dysf_chroma_kernel"] = {"ms": round(k_chroma, 4)}
-        if cnn is not None:   # configs[2]: the dominant kernel is the CNN's conv2 (implicit GEMM on MFMA)
+        if cnn is not None and args.config != 5:   # configs[2]: the dominant kernel is the CNN's conv2 (implicit GEMM on MFMA)
             flops = BATCH * (2 * 32 * 9 * 120 * 301 + 2 * 64 * 32 * 9 * 60 * 150)
             tf = flops / (cnn_ms * 1e-3) / 1e12
             prec = getattr(cnn, "precision", "f16")
@@ -424,6 +487,26 @@ def main():
                                "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
                                "algorithmic_flops_per_launch": flops, "kernel_ms": round(cnn_ms, 4), "conv2_precision": prec,
                                "feature_kernels_ms": round(k_path, 4)}
+        if args.config == 5:
+            T5 = lens // params.hop + 1
+            flops5 = int((2 * 32 * 9 * 60 * T5 + 2 * 64 * 32 * 9 * 30 * (T5 // 2)).sum())
+            tf5 = flops5 / (cnn5_ms * 1e-3) / 1e12
+            out["config"].update({
+                "workload": "BASELINE.json configs[4]: per GPU 1024 clips with lengths ~ U[1, 10] s at 22 050 Hz (seed 4321 + rank; no resampling, the "
+                            "rate is a parameter), 2048-pt STFT hop 512, 128 Slaney mels, 20 MFCC + delta + delta2; clips grouped by ceil(seconds) into "
+                            "10 buckets, one ragged launch per bucket padded to the bucket's longest clip, CNN head in float16 MFMA with the clips' "
+                            "true widths, logits back in clip order, (N>1) RCCL all-gather",
+                "sr": sr5, "seed": 4321, "clips_per_bucket": {str(int(np.ceil(b["max"] / sr5))): b["n"] for b in buckets},
+                "samples_per_gpu": total_samples5, "samples_per_clip": None, "frames_per_clip": None,
+                "hours_of_audio_per_s": round(total_samples5 * world / sr5 / 3600 / (dt / args.steps), 1),
+                "feature_launches_ms": round(feat5_ms, 4), "cnn_launches_ms": round(cnn5_ms, 4), "head": "cnn (float16 MFMA conv2)"})
+            out["dtype"] = "f16"
+            out["roofline"] = {"bound": "mfma", "kernel": "dysf_cnn_* over the ten buckets (conv1 + pool + conv2 + average + linear, per-clip widths)",
+                               "achieved": round(tf5, 2), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf5 / MFMA_F16_PEAK_TF, 4),
+                               "traffic": None, "algorithmic_flops_per_launch": flops5, "kernel_ms": round(cnn5_ms, 4),
+                               "feature_kernels_ms": round(feat5_ms, 4),
+                               "feature_algorithmic_bytes": int(2 * total_samples5 + 4 * 60 * int(T5.sum())),
+                               "feature_achieved_gbs": round((2 * total_samples5 + 4 * 60 * int(T5.sum())) / (feat5_ms * 1e-3) / 1e9, 1)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

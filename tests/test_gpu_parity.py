@@ -768,6 +768,15 @@ def test_bench_cnn_head_full_batch():
     assert d["config"]["head"] == "cnn" and d["value"] > 0 and d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_config5_ragged_buckets_cnn():
+    """BASELINE configs[4] through bench.py: 1-10 s clips at 22.05 kHz in ten length buckets, ragged launches, float16-MFMA CNN
+    with per-clip widths; the chosen numbers are echoed into the JSON."""
+    d = _run_bench("--config", "5", "--steps", "3", "--warmup", "1", "--bank-workers", "2")
+    c = d["config"]
+    assert c["sr"] == 22050 and c["seed"] == 4321 and sum(c["clips_per_bucket"].values()) == 1024 and len(c["clips_per_bucket"]) >= 9
+    assert d["dtype"] == "f16" and d["roofline"]["bound"] == "mfma" and d["value"] > 0 and c["hours_of_audio_per_s"] > 0
+
+
 def test_bench_config4_two_ranks_rehearsal():
     """BASELINE configs[3] through the same self-launch path: 100 000 clips in two 50 000-clip shards (extract_large over the
     lanes), one all-gather of [50 000, 3] logits, gathered arg-max equal to the single-GPU result."""

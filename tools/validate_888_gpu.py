@@ -35,6 +35,15 @@ for i in np.nonzero(per_clip_chroma > 1e-4)[0]:
     _, dbg = O.estimate_tuning(O.stft_power(O.pcm16_to_float(clips[i]), O.REFERENCE_149), O.REFERENCE_149)
     tun_mis.append({"stem": idx[i]["stem"], "gpu_index": int(res["tuning"][i]), "oracle_index": int(dbg["index"]),
                     "chroma_max_abs_diff": float(per_clip_chroma[i])})
+# per-file metrics (pipeline1.py:151-186) of all 888 clips against the reference's per_file_analysis.csv values
+met = None
+have = [i for i, e in enumerate(idx) if e.get("metrics_after")]
+if have:
+    gm = rsd_amd.audio_metrics_batch([clips[i] for i in have], 16000)
+    wm = np.array([idx[i]["metrics_after"] for i in have])
+    met = {"n_clips": len(have), "snr_db_max_abs_diff": float(np.abs(gm[:, 0] - wm[:, 0]).max()),
+           "flatness_max_rel_diff": float((np.abs(gm[:, 1] - wm[:, 1]) / np.maximum(np.abs(wm[:, 1]), 1e-12)).max()),
+           "hf_ratio_max_rel_diff": float((np.abs(gm[:, 2] - wm[:, 2]) / np.maximum(np.abs(wm[:, 2]), 1e-12)).max())}
 rec = {
     "what": "GPU path (rsd_amd REFERENCE_149, one batched launch of 888 clips) vs reference cache_features/*_clean_feats.npy",
     "n_pairs": len(clips), "all_status_ok": bool((res["status"] == 0).all()),
@@ -47,6 +56,7 @@ rec = {
     "chroma_block": {"n_over_1e-4": int((per_clip_chroma > 1e-4).sum()), "median": float(np.median(per_clip_chroma)),
                      "clips_over_1e-4": tun_mis},
     "tuning_index_equal_to_oracle": tun_all_equal,
+    "metrics_vs_per_file_analysis_csv": met,
     "n_clips_all_149_within_1e-4": int((D.max(axis=1) <= 1e-4).sum()),
 }
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
