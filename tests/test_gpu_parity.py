@@ -316,6 +316,27 @@ def test_full_batch_properties_bench_config(ex512):
     assert float((po.double() - want).abs().max()) <= 1e-4
 
 
+def test_full_batch_properties_reference_preset(ex149):
+    """The reference's own parameterisation at the bench batch size (1024 clips x 3 s resident in HBM, parity mode):
+    identical clips give bit-identical rows and tuning indices wherever they sit in the batch, a sample matches the oracle
+    (pooled 1e-4, tuning exact), statuses are clean."""
+    bank = np.stack([synth_clip(i) for i in range(16)])
+    idx = np.arange(1024) % 16
+    pcm = torch.from_numpy(bank[idx].reshape(-1)).cuda()
+    off = torch.arange(0, 1025, dtype=torch.int64, device="cuda") * 48000
+    res = ex149.extract_batch_device(pcm, off, 48000, pooled=True, tuning=True)
+    torch.cuda.synchronize()
+    po, tu = res["pooled"], res["tuning"]
+    assert po.shape == (1024, 144) and int(res["status"].abs().sum()) == 0
+    for r in range(1, 64):
+        assert torch.equal(po[r * 16:(r + 1) * 16], po[:16]) and torch.equal(tu[r * 16:(r + 1) * 16], tu[:16])
+    for j in (0, 7, 15):
+        y = O.pcm16_to_float(bank[j])
+        want = O.extract_audio_features(y, 16000)
+        assert np.abs(po[1008 + j].cpu().numpy() - want).max() <= 1e-4
+        assert int(tu[1008 + j]) == O.estimate_tuning(O.stft_power(y, O.REFERENCE_149), O.REFERENCE_149)[1]["index"]
+
+
 def test_mlp_head_argmax_on_gpu(golden_dir):
     from rsd_amd.classifier import MLPHead
     z = np.load(os.path.join(golden_dir, "classifier_after.npz"))
