@@ -1129,7 +1129,9 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
 // streams their spectrum rows straight from HBM into MFMA B operands (16 bytes per lane, eight loads in flight):
 // K is walked in groups of 16 bins, lane (frame = l & 15, q = l >> 4) holding the four consecutive bins 16g + 4q + s,
 // and the bank pack has the same order ([tuning][group][lane][4]), so there is no LDS staging and no second FFT.
-template <int NC, int NT>
+// NVT: 256-bin slices of a row held in registers per frame by the peak pass (3 covers the pitch band up to bin 767, which is
+// every preset at 16 kHz and above; the full-width instantiation serves lower sample rates).
+template <int NC, int NT, int NVT>
 __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   extern __shared__ __align__(16) float4 sm_cand[];   // [2 * NW frames][(pip_kmax - pip_kmin) / 2 + 2] parked local maxima (they cannot be adjacent)
@@ -1159,7 +1161,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     // Two frames per wave and round; a lane owns four consecutive bins of every 256-bin slice of its frame's row (one
     // 16-byte load per slice, all slices of both frames requested before the first is looked at), the neighbours of
     // its first and last bin come from the adjacent lanes.
-    constexpr int NV = (NC + 1 + 255) / 256;       // 256-bin slices that cover bins 0 .. NC
+    constexpr int NV = NVT;                        // 256-bin slices held per frame (the launcher checks that they reach pip_kmax)
     constexpr int FPR = 2;                         // frames per wave per round
     const float* rowmax = a.ws_rowmax + (size_t)clip * a.t_max;
     const int nv = min(NV, (a.pip_kmax + 1 + 255) / 256);   // slices that reach the pitch band (wave-uniform)
@@ -1236,9 +1238,23 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     if (npk & 1) {
       thr = block_select<NT>(pk_mag, npk, npk / 2, sm_i + 128, sm_i);
     } else {
+      // np.median of an even count: mean of the two middle order statistics.  The upper one follows from the lower one in a
+      // single pass: it is the lower value again if that value fills index npk / 2 too, else the smallest larger element.
       const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, sm_i + 128, sm_i);
-      const float hi = block_select<NT>(pk_mag, npk, npk / 2, sm_i + 128, sm_i);
+      if (tid == 0) { sm_i[2] = 0; sm_i[3] = 0x7f800000; }
+      __syncthreads();
+      int c_le = 0;
+      unsigned mn = 0x7f800000u;   // +inf; the magnitudes that matter are positive floats: their bits order like the values
+      for (int i = tid; i < npk; i += NT) {
+        const float x = pk_mag[i];
+        if (x <= lo) ++c_le; else mn = min(mn, __float_as_uint(x));
+      }
+      atomicAdd(&sm_i[2], c_le);
+      atomicMin((unsigned*)&sm_i[3], mn);
+      __syncthreads();
+      const float hi = (sm_i[2] > npk / 2) ? lo : __uint_as_float((unsigned)sm_i[3]);
       thr = mul_rn(add_rn(lo, hi), 0.5f);
+      __syncthreads();
     }
     if (tid < kTunings) hist[tid] = 0;
     __syncthreads();
@@ -1667,16 +1683,23 @@ hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int NC>
+static hipError_t launch_chroma_nc(const KArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  constexpr int NVF = (NC + 1 + 255) / 256;          // slices that cover bins 0 .. NC
+  constexpr int NVS = NVF < 3 ? NVF : 3;
+  if ((a.pip_kmax + 1 + 255) / 256 <= NVS) hipLaunchKernelGGL((dysf_chroma_kernel<NC, 512, NVS>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((dysf_chroma_kernel<NC, 512, NVF>), grid, dim3(512), lds, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s) {
   const size_t lds = (size_t)a.cand_cap * sizeof(float4);   // <= 64 KB: no attribute needed
   switch (n_fft) {
-    case 256: hipLaunchKernelGGL((dysf_chroma_kernel<128, 512>), grid, dim3(512), lds, s, a); break;
-    case 512: hipLaunchKernelGGL((dysf_chroma_kernel<256, 512>), grid, dim3(512), lds, s, a); break;
-    case 1024: hipLaunchKernelGGL((dysf_chroma_kernel<512, 512>), grid, dim3(512), lds, s, a); break;
-    case 2048: hipLaunchKernelGGL((dysf_chroma_kernel<1024, 512>), grid, dim3(512), lds, s, a); break;
+    case 256: return launch_chroma_nc<128>(a, grid, lds, s);
+    case 512: return launch_chroma_nc<256>(a, grid, lds, s);
+    case 1024: return launch_chroma_nc<512>(a, grid, lds, s);
+    case 2048: return launch_chroma_nc<1024>(a, grid, lds, s);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace dysf
