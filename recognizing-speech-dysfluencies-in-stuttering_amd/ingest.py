@@ -101,7 +101,10 @@ class StreamingExtractor:
         if t.is_pinned():
             return t, False
         if allow_register and pcm.nbytes > 0:
-            rc = torch.cuda.cudart().cudaHostRegister(pcm.ctypes.data, pcm.nbytes, 0)
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(pcm.ctypes.data, pcm.nbytes, 0)
+            except Exception:      # a runtime without the call: stage through pinned buffers instead
+                return None, False
             if int(rc) == 0:
                 return t, True
         return None, False
@@ -183,7 +186,10 @@ class StreamingExtractor:
         finally:
             if registered:
                 torch.cuda.synchronize(dev)
-                torch.cuda.cudart().cudaHostUnregister(pcm.ctypes.data)
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(pcm.ctypes.data)
+                except Exception:
+                    pass
             if pool is not None:
                 pool.shutdown()
         return {"pooled": pooled.numpy(), "status": status.numpy()}

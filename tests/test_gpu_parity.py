@@ -418,6 +418,36 @@ def test_sub_batched_launch_equals_single_launch(monkeypatch):
         assert np.array_equal(ref[k], got[k]), k
 
 
+def test_sub_batched_launch_parity_preset_and_metrics(monkeypatch):
+    """The same for the chroma / parity preset (spectrogram, row maxima, peak lists, frame-row stash per sub-batch) and for
+    the metrics launch (flatness rows, frame energies, chirp-z buffers)."""
+    clips = [synth_clip(i % 5, n=9000 + 1700 * (i % 4)) for i in range(14)]
+    ref_ex = rsd_amd.FeatureExtractor(P149, 0)
+    ref = ref_ex.extract_batch(clips, tuning=True)
+    ref_m = rsd_amd.audio_metrics_batch(clips, 16000)
+    monkeypatch.setenv("DYSF_WS_MB", "2")   # a few clips per sub-batch
+    small = rsd_amd.FeatureExtractor(P149, 0)
+    got = small.extract_batch(clips, tuning=True)
+    for k in ("pooled", "status", "tuning"):
+        assert np.array_equal(ref[k], got[k]), k
+    rsd_amd.features._extractors.clear()    # audio_metrics_batch caches its extractor: force one that sees DYSF_WS_MB
+    got_m = rsd_amd.audio_metrics_batch(clips, 16000)
+    rsd_amd.features._extractors.clear()
+    assert np.array_equal(ref_m, got_m)
+    small.close(); ref_ex.close()
+
+
+def test_tuning_only_call_equals_full_call(ex149):
+    """dysf_extract_batch_dev with only the tuning output requested (no pooled rows): the estimate is still computed."""
+    clips = [synth_clip(30 + i, n=20000 + 3000 * i) for i in range(4)]
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    off = torch.tensor(np.concatenate([[0], np.cumsum([len(c) for c in clips])]), dtype=torch.int64, device="cuda")
+    full = ex149.extract_batch_device(pcm, off, max(len(c) for c in clips), pooled=True, tuning=True)
+    only = ex149.extract_batch_device(pcm, off, max(len(c) for c in clips), pooled=False, tuning=True)
+    torch.cuda.synchronize()
+    assert torch.equal(full["tuning"], only["tuning"]) and len(set(full["tuning"].tolist())) > 1
+
+
 def test_cnn_head_fp16_agreement(ex512):
     """configs[4] asks for the CNN in fp16: report agreement with the fp32 head (random weights, so no oracle)."""
     from rsd_amd.classifier import CNNHead
