@@ -109,7 +109,7 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
  *              zero-filled), or NULL
  *   d_status   [n_clips] int32, or NULL
  *   d_tuning   [n_clips] int32 tuning-histogram index 0..99 (tuning = -0.5 + 0.01*idx), or NULL
- *   stream     hipStream_t (NULL = default stream).  The call only enqueues work (a memset and two or three kernels).
+ *   stream     hipStream_t (NULL = default stream).  The call only enqueues work (at most a small memset and two to four kernels).
  */
 int32_t dysf_extract_batch_dev(DysfHandle* h, const void* d_pcm, int32_t pcm_type,
                                const int64_t* d_offsets, int32_t n_clips, int64_t max_samples,

@@ -336,7 +336,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
   if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
 
-  // ---- kernel C geometry (chroma): 512 threads, one workgroup per clip
+  // ---- kernel D geometry (rich presets: its own float32 STFT pass): 512 threads, one workgroup per clip
   const int nw_c = 8, fpi_c = t.FPW * nw_c, cb_c = (fpi_c + 15) / 16;
   const int tile_c = ((fpi_c - 1) * p.hop + p.n_fft + 8 + 7) & ~7;
   const int misc_c = (128 + nw_c * cb_c * 256 + 16 * cb_c * 16 + 3) & ~3;
@@ -397,8 +397,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int tiles_max = (int)((t_max + fpi_a - 1) / fpi_a);
   const int groups = (tiles_max + a.tiles_per_wg - 1) / a.tiles_per_wg;
   if (std::getenv("DYSF_VERBOSE"))
-    std::fprintf(stderr, "[dysf] stft: %d thr, grid %dx%lld, lds %zu B | mfcc: lds %zu B | chroma: lds %zu B | sub-batch %lld clips, slots %d\n",
-                 nt_a, groups, (long long)sub, lds_a, lds_b, p.chroma ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
+    std::fprintf(stderr, "[dysf] stft: %d thr, grid %dx%lld, lds %zu B | mfcc: lds %zu B | rich: lds %zu B | sub-batch %lld clips, slots %d\n",
+                 nt_a, groups, (long long)sub, lds_a, lds_b, p.rich ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
 
   h->last_sub = sub; h->last_peak_stride = a.ws_peak_stride;
   for (int64_t c0 = 0; c0 < n_clips; c0 += sub) {

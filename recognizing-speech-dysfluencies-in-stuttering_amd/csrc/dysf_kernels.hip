@@ -1,16 +1,20 @@
 // dysf_kernels.hip -- gfx950 kernels for the dysfluency feature path.
 //
-// librosa.feature.mfcc -> delta -> delta(order=2) -> stat_pair (+ chroma_stft), pipeline1.py:216-228, as three
-// kernels on one stream.  The only HBM intermediate is the log-mel spectrogram (clip-global top_db needs the
-// whole clip before the DCT); everything else lives in registers and LDS.
-//   dysf_stft_mel_kernel  grid (tile groups, clips), small LDS footprint -> 3-4 workgroups per CU:
-//            coalesced PCM -> LDS tile; per-wave register FFT (dysf_fft.hpp) -> power-spectrum tile in LDS;
-//            banded Slaney-mel GEMM on v_mfma_f32_16x16x4_f32 (split-K schedule); 10*log10 -> log-mel
-//            [n_mels][T] in the workspace; clip max by atomicMax; optional piptrack peak picking
-//   dysf_mfcc_kernel      one workgroup per clip: clip-global top_db clamp, DCT-II on the float64 MFMA,
-//            Savitzky-Golay deltas, frame-level rows [3*n_mfcc][T], pooled mean/std
-//   dysf_chroma_kernel    (chroma only) one workgroup per clip: median / histogram tuning decision, second
-//            STFT pass, chroma GEMM on MFMA against the selected one of 100 banks, max-norm, mean/std
+// librosa.feature.mfcc -> delta -> delta(order=2) -> stat_pair (+ chroma_stft), pipeline1.py:216-228, as two kernels on
+// one stream (three with chroma).  The HBM intermediates are the log-mel spectrogram (clip-global top_db needs the whole
+// clip before the DCT) and, for chroma presets, the power spectrogram (librosa's second STFT is not recomputed).
+//   dysf_stft_mel_kernel  grid (tile groups, clips), small LDS footprint -> 4 workgroups per CU:
+//            coalesced PCM -> LDS tile; per-wave register FFT (dysf_fft.hpp; float64 in the parity presets) ->
+//            power-spectrum tile in LDS; banded Slaney-mel GEMM on v_mfma_f32_16x16x4_f32 (split-K schedule);
+//            10*log10 -> log-mel [T][n_mels] in the workspace; clip max of the mel power by atomicMax; chroma presets:
+//            spectrogram rows and row maxima to the workspace; metrics launches: per-frame spectral flatness
+//   dysf_mfcc_kernel      one workgroup per clip: clip-global top_db clamp, DCT-II on the MFMA, Savitzky-Golay deltas,
+//            frame-level rows [3*n_mfcc][T], pooled mean/std (NumPy's float32 summation order in the parity presets)
+//   dysf_chroma_kernel    (chroma only) one workgroup per clip: piptrack peak picking on the stored spectrogram,
+//            median / histogram tuning decision, chroma GEMM on MFMA against the selected one of 100 banks, max-norm,
+//            mean/std
+//   dysf_rich_kernel      (rich presets, main.py:738-754) spectral contrast, zero-crossing rate, RMS, centroid
+//   dysf_metrics_kernel   (metrics launches, pipeline1.py:151-174) snr_db and the mean spectral flatness
 #include <hip/hip_runtime.h>
 
 #include "dysf_fft.hpp"
