@@ -220,7 +220,7 @@ def test_audio_metrics_match_reference_csv_and_oracle(golden_dir):
     y = O.pcm16_to_float(clips[3])
     assert abs(rsd_amd.snr_db(y) - want[3, 0]) <= 2e-4 and abs(rsd_amd.high_freq_energy_ratio(y, 16000) - want[3, 2]) <= 2e-5 * want[3, 2]
     assert rsd_amd.snr_db(None) == 0.0
-    odd = [synth_clip(5, n=n) for n in (7919, 48000, 30011, 300, 4099)] + [np.zeros(9000, np.int16)]
+    odd = [synth_clip(5, n=n) for n in (7919, 48000, 30011, 300, 4099, 160001)] + [np.zeros(9000, np.int16)]   # 160001: a 2^19 chirp-z transform
     got = rsd_amd.audio_metrics_batch(odd, 16000)
     for i, c in enumerate(odd):
         w = O.audio_metrics(O.pcm16_to_float(c), 16000)
