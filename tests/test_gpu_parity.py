@@ -813,6 +813,22 @@ def test_bench_two_ranks_rehearsal():
     assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 2e-4
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's form: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (ranks from the
+    environment; the script must not start ranks of its own then)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--share-gpu", "--no-cpu-baseline", "--bank-workers", "2"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+
+
 def test_bench_cnn_head_full_batch():
     """BASELINE configs[2] at its full size through bench.py: 1024 clips, frame rows -> HIP CNN head, MFMA roofline entry."""
     d = _run_bench("--head", "cnn", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--bank-workers", "2")
