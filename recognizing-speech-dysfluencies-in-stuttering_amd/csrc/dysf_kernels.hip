@@ -138,6 +138,19 @@ __device__ __forceinline__ bool pcm_store_group(float* tile, int gi, int4 v) {
 
 template <int PCM, int NT>
 __device__ __forceinline__ void pcm_prefetch(PcmStage<PCM>& st, const char* base, int n, int r0, int ngroups) {
+  constexpr int EPG = PcmStage<PCM>::EPG;
+  constexpr int ES = (PCM == DYSF_PCM_I16) ? 2 : 4;
+  // A tile that lies inside the clip (all but the first and last one or two of a clip; the test is wave-uniform) takes
+  // plain 16-byte loads: the group index is clamped instead of guarded -- the surplus lanes reload the last group and
+  // pcm_commit does not store them -- so the path has no exec-mask branches at all.
+  if (r0 >= 0 && r0 + ngroups * EPG <= n) {
+#pragma unroll
+    for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
+      const int gi = min((int)threadIdx.x + j * NT, ngroups - 1);
+      st.g[j] = *(const int4*)(base + (long long)(r0 + gi * EPG) * ES);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < PcmStage<PCM>::MAXG; ++j) {
     const int gi = threadIdx.x + j * NT;
