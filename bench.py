@@ -386,7 +386,7 @@ def main():
         host_rate = None
         if world == 1 and not args.no_host_rate and args.config == 2 and cnn is None:
             from rsd_amd.ingest import StreamingExtractor, pinned_empty
-            n_host = 16384
+            n_host = 32768   # 3.1 GB of int16 PCM: the pipeline's fill (first chunk's copy, not overlapped) is 1/16 of the run
             hoff = np.arange(n_host + 1, dtype=np.int64) * N_SAMPLES
             host_rate = {"clips": n_host}
             # (i) the producer decodes into page-locked memory (pinned_empty): H2D starts straight from it;
