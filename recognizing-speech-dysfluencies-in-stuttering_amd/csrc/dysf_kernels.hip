@@ -1681,7 +1681,7 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
 }
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   // up to 64 mels: mean-free float32 MFMA.  The eight-group form of it spills its statistics accumulators, so the
-  // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tools/margin.py).
+  // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tests/diagnostics/margin.py).
   if (a.dct_pack32 && a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, true>, grid, 512, lds_bytes, s, a);
   if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
   return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);

@@ -1,6 +1,6 @@
 """Diagnostic: parity preset on a few fixture clips -- frame rows vs oracle, pooled vs NumPy statistics of the GPU's own rows."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import rsd_amd

@@ -1,7 +1,7 @@
 """GPU-side diagnostic: where does the pooled-vector error of one reference pair come from?"""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import rsd_amd
 from oracle import dysf_oracle as O

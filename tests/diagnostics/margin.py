@@ -1,7 +1,7 @@
 """GPU diagnostic: error margins of the bench preset (BENCH_512) against the CPU oracle on synthetic clips, pooled and
-frame level.  usage: python tools/margin.py [n_clips]   (DYSF_DCT64=1 selects the float64-MFMA DCT for comparison)"""
+frame level.  usage: python tests/diagnostics/margin.py [n_clips]   (DYSF_DCT64=1 selects the float64-MFMA DCT for comparison)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch  # noqa: F401
 import rsd_amd

@@ -132,7 +132,7 @@ def copy_pairs(lengths):
 
 
 def export_all(lengths):
-    """All 888 pairs into tests/golden/_all888/ (git-ignored, never committed): input of tools/validate_888_gpu.py, which
+    """All 888 pairs into tests/golden/_all888/ (git-ignored, never committed): input of tests/golden/validate_888_gpu.py, which
     runs on the GPU box where /root/reference does not exist."""
     out = os.path.join(HERE, "_all888")
     shutil.rmtree(out, ignore_errors=True)

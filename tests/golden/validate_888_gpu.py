@@ -2,7 +2,7 @@
 The pairs are copied into tests/golden/_all888/ (git-ignored, never committed) by the build container; this script runs on
 the GPU box and writes the summary JSON that IS committed (tests/golden/validate_888_gpu.json)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import rsd_amd
