@@ -818,20 +818,27 @@ __device__ __forceinline__ float pw_leaf(const float* x, int n, int j, int pass,
 // DCT (8 halo frames each side of the chunk), then owns the MFCC rows c = wave, wave + NW, ... (a lane is a frame).
 // Mean / variance are one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane
 // partials across the chunks, one float64 reduction per clip.
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBShift = 0;     // float[48][3]: frame-0 features
 constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-byte aligned)
 
-template <int NT, int NG, bool F32>
+// RB = 1..3 fixes the geometry at compile time (n_mels == 16 * NG, dct_rb == RB: no mel masks, no per-block branches,
+// constant LDS offsets); RB = 0 reads it from the arguments.
+template <int NT, int NG, bool F32, int RB>
 __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   constexpr int COLS = 16 * NW;
   constexpr int CH = COLS - 16;
-  constexpr int CSTR = kMfccCstr;         // LDS row stride of the MFCC chunk (the DCT tile writes of rows 4 apart miss each other's banks)
+  constexpr int CSTR = kMfccCstr;         // LDS row stride of the MFCC chunk: NW * CSTR is a multiple of 64 (paired ds_read2st64 taps)
+  static_assert((NW * CSTR) % 64 == 0 && 16 % (2 * NW) == 0, "row pairs of the delta pass");
   constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
   extern __shared__ __align__(16) float lds[];
   STAMP_INIT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row bases and store addresses stay in SGPRs
+  __builtin_assume(wave >= 0 && wave < NW);
+  const int groups = RB ? NG : a.dct_groups;   // K groups of 16 mels
+  const int rbs = RB ? RB : a.dct_rb;          // row blocks of 16 coefficients
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
   const long long off = a.offsets[clip];
@@ -868,12 +875,12 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   float* kshift = lds + kBShift;
   double* dct = (double*)(lds + kBDct);
   const float* dct32 = lds + kBDct;               // F32: float A operands, then the float64 row sums of the coefficients
-  const int nd = a.dct_rb * a.dct_groups * 256;
+  const int nd = rbs * groups * 256;
   const double* rowsum = (const double*)(lds + kBDct + nd);
-  float* chunk = lds + kBDct + (F32 ? nd + 2 * 16 * a.dct_rb : 2 * nd);
+  float* chunk = lds + kBDct + (F32 ? nd + 2 * 16 * rbs : 2 * nd);
   if (F32) {
     for (int i = tid * 4; i < nd; i += NT * 4) *(float4*)(lds + kBDct + i) = *(const float4*)(a.dct_pack32 + i);
-    for (int i = tid; i < 16 * a.dct_rb; i += NT) ((double*)(lds + kBDct + nd))[i] = a.dct_rowsum[i];
+    for (int i = tid; i < 16 * rbs; i += NT) ((double*)(lds + kBDct + nd))[i] = a.dct_rowsum[i];
   } else {
     for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
   }
@@ -882,11 +889,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   float* wrow = frow;
   long long wstr = a.frame_stride;
   if (!wrow && a.parity && prow) { wrow = a.ws_stat + (size_t)clip * 3 * C * a.stat_stride; wstr = a.stat_stride; }
-  float ps[RPW][6];
+  f2 ps[RPW / 2][6];  // [row pair][sum x, d, dd, then the squares]: lane partials of e = feature - frame-0 feature
 #pragma unroll
-  for (int i = 0; i < RPW; ++i)
+  for (int i = 0; i < RPW / 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) ps[i][j] = 0.f;
+    for (int j = 0; j < 6; ++j) ps[i][j] = f2{0.f, 0.f};
   // The log-mel rows of a chunk are fetched one chunk ahead: the loads of chunk i+1 fly during the delta pass of chunk i
   // (NG = 16-mel groups held in registers; rows past the clip clamp to the last frame, so the extra fetch is harmless).
   float4 pf[NG];
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     const float* lrow = lm + (size_t)t * a.lm_stride + 4 * (lane >> 4);  // this lane's four mels of every 16-mel group
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-      if (g < a.dct_groups) pf[g] = *(const float4*)(lrow + 16 * g);  // 16 frames x 64 bytes per wave load
+      if (g < groups) pf[g] = *(const float4*)(lrow + 16 * g);  // 16 frames x 64 bytes per wave load
   };
   fetch(0);
   STAMP(8);  // setup
@@ -919,12 +926,12 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (g < a.dct_groups) {
+        if (g < groups) {
           const int m0 = 16 * g + 4 * (lane >> 4);
-          xq[g].x = (m0 + 0 < a.n_mels) ? fmaxf(pf[g].x, floor_db) : 0.f;
-          xq[g].y = (m0 + 1 < a.n_mels) ? fmaxf(pf[g].y, floor_db) : 0.f;
-          xq[g].z = (m0 + 2 < a.n_mels) ? fmaxf(pf[g].z, floor_db) : 0.f;
-          xq[g].w = (m0 + 3 < a.n_mels) ? fmaxf(pf[g].w, floor_db) : 0.f;
+          xq[g].x = (RB || m0 + 0 < a.n_mels) ? fmaxf(pf[g].x, floor_db) : 0.f;
+          xq[g].y = (RB || m0 + 1 < a.n_mels) ? fmaxf(pf[g].y, floor_db) : 0.f;
+          xq[g].z = (RB || m0 + 2 < a.n_mels) ? fmaxf(pf[g].z, floor_db) : 0.f;
+          xq[g].w = (RB || m0 + 3 < a.n_mels) ? fmaxf(pf[g].w, floor_db) : 0.f;
           sum += (xq[g].x + xq[g].y) + (xq[g].z + xq[g].w);
         }
       }
@@ -937,17 +944,17 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       for (int rb = 0; rb < 3; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (g < a.dct_groups) {
+        if (g < groups) {
           const int m0 = 16 * g + 4 * (lane >> 4);
           float bv[4];
-          bv[0] = (m0 + 0 < a.n_mels) ? xq[g].x - m32 : 0.f;
-          bv[1] = (m0 + 1 < a.n_mels) ? xq[g].y - m32 : 0.f;
-          bv[2] = (m0 + 2 < a.n_mels) ? xq[g].z - m32 : 0.f;
-          bv[3] = (m0 + 3 < a.n_mels) ? xq[g].w - m32 : 0.f;
+          bv[0] = (RB || m0 + 0 < a.n_mels) ? xq[g].x - m32 : 0.f;
+          bv[1] = (RB || m0 + 1 < a.n_mels) ? xq[g].y - m32 : 0.f;
+          bv[2] = (RB || m0 + 2 < a.n_mels) ? xq[g].z - m32 : 0.f;
+          bv[3] = (RB || m0 + 3 < a.n_mels) ? xq[g].w - m32 : 0.f;
 #pragma unroll
           for (int rb = 0; rb < 3; ++rb) {
-            if (rb < a.dct_rb) {
-              const float4 a4 = *(const float4*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
+            if (rb < rbs) {
+              const float4 a4 = *(const float4*)(dp + (rb * groups + g) * 256);
               acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bv[0], acc[rb], 0, 0, 0);
               acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bv[1], acc[rb], 0, 0, 0);
               acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bv[2], acc[rb], 0, 0, 0);
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       }
 #pragma unroll
       for (int rb = 0; rb < 3; ++rb)
-        if (rb < a.dct_rb)
+        if (rb < rbs)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // f32 C/D map: row = 4 * (lane >> 4) + reg, col = lane & 15
             const int row = rb * 16 + 4 * (lane >> 4) + r;
@@ -971,19 +978,19 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
         for (int rb = 0; rb < 3; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
   #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          if (g < a.dct_groups) {
+          if (g < groups) {
             const float4 b4 = pf[g];
             const int m0 = 16 * g + 4 * (lane >> 4);
             double bv[4];
-            bv[0] = (m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
-            bv[1] = (m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
-            bv[2] = (m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
-            bv[3] = (m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
+            bv[0] = (RB || m0 + 0 < a.n_mels) ? (double)fmaxf(b4.x, floor_db) : 0.0;
+            bv[1] = (RB || m0 + 1 < a.n_mels) ? (double)fmaxf(b4.y, floor_db) : 0.0;
+            bv[2] = (RB || m0 + 2 < a.n_mels) ? (double)fmaxf(b4.z, floor_db) : 0.0;
+            bv[3] = (RB || m0 + 3 < a.n_mels) ? (double)fmaxf(b4.w, floor_db) : 0.0;
   #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
-              if (rb < a.dct_rb) {
-                const double2 a01 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256);
-                const double2 a23 = *(const double2*)(dp + ((size_t)rb * a.dct_groups + g) * 256 + 2);
+              if (rb < rbs) {
+                const double2 a01 = *(const double2*)(dp + (rb * groups + g) * 256);
+                const double2 a23 = *(const double2*)(dp + (rb * groups + g) * 256 + 2);
                 acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, bv[0], acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, bv[1], acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, bv[2], acc[rb], 0, 0, 0);
@@ -996,7 +1003,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
         fetch(t0 + CH);
   #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
-          if (rb < a.dct_rb)
+          if (rb < rbs)
   #pragma unroll
             for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
               chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
@@ -1013,32 +1020,49 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       const int bx = (tv ? t : t0) - (t0 - 8);  // column of frame t in the chunk
       const int bc = tc - (t0 - 8);             // column of the delta centre
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int c = wave + i * NW;
-        if (c < C) {
-          const float* row = chunk + c * CSTR;
-          const float x = row[bx];
-          float d = 0.f, dd = 0.f;
+      for (int p = 0; p < RPW / 2; ++p) {
+        // two rows per pass: c0 and c1 = c0 + NW lie NW * CSTR floats (a multiple of 64) apart, so every tap is one
+        // ds_read2st64_b32 whose register pair feeds packed float32 math directly.  Rows between n_mfcc and the end of
+        // their 16-row block are zero rows of the DCT pack; they ride along unused.
+        const int c0 = wave + 2 * p * NW, c1 = c0 + NW;
+        if (c0 < 16 * rbs) {
+          const float* r0 = chunk + c0 * CSTR;
+          const float* r1 = r0 + NW * CSTR;
+          auto ld = [&](int col) { return f2{r0[col], r1[col]}; };
+          const f2 x = ld(bx);
+          f2 d = f2{0.f, 0.f}, dd = f2{0.f, 0.f};
           if (tv) {
-            const float xc = row[bc], x2 = xc + xc;
-            const float p1 = row[bc + 1], m1 = row[bc - 1], p2 = row[bc + 2], m2 = row[bc - 2];
-            const float p3 = row[bc + 3], m3 = row[bc - 3], p4 = row[bc + 4], m4 = row[bc - 4];
+            const f2 xc = ld(bc), x2 = xc + xc;
+            const f2 p1 = ld(bc + 1), m1 = ld(bc - 1), p2 = ld(bc + 2), m2 = ld(bc - 2);
+            const f2 p3 = ld(bc + 3), m3 = ld(bc - 3), p4 = ld(bc + 4), m4 = ld(bc - 4);
             d = ((p1 - m1) + 2.f * (p2 - m2) + 3.f * (p3 - m3) + 4.f * (p4 - m4)) * (1.0f / 60.0f);
             dd = (28.f * ((p4 + m4) - x2) + 7.f * ((p3 + m3) - x2) - 8.f * ((p2 + m2) - x2) - 17.f * ((p1 + m1) - x2)) *
                  (1.0f / 462.0f);
           }
+          float* k0 = kshift + c0 * 3;
+          float* k1 = kshift + c1 * 3;
           if (t0 == 0 && sub == 0) {  // shift values = the features of frame 0
-            if (lane == 0) { kshift[c * 3 + 0] = x; kshift[c * 3 + 1] = d; kshift[c * 3 + 2] = dd; }
+            if (lane == 0) {
+              k0[0] = x[0]; k0[1] = d[0]; k0[2] = dd[0];
+              k1[0] = x[1]; k1[1] = d[1]; k1[2] = dd[1];
+            }
             wave_lds_sync();
           }
           if (tv) {
-            const float e0 = x - kshift[c * 3 + 0], e1 = d - kshift[c * 3 + 1], e2 = dd - kshift[c * 3 + 2];
-            ps[i][0] += e0; ps[i][1] += e1; ps[i][2] += e2;
-            ps[i][3] += e0 * e0; ps[i][4] += e1 * e1; ps[i][5] += e2 * e2;
+            const f2 e0 = x - f2{k0[0], k1[0]}, e1 = d - f2{k0[1], k1[1]}, e2 = dd - f2{k0[2], k1[2]};
+            ps[p][0] += e0; ps[p][1] += e1; ps[p][2] += e2;
+            ps[p][3] += e0 * e0; ps[p][4] += e1 * e1; ps[p][5] += e2 * e2;
             if (wrow) {
-              wrow[(size_t)c * wstr + t] = x;
-              wrow[(size_t)(C + c) * wstr + t] = d;
-              wrow[(size_t)(2 * C + c) * wstr + t] = dd;
+              if (c0 < C) {
+                wrow[(size_t)c0 * wstr + t] = x[0];
+                wrow[(size_t)(C + c0) * wstr + t] = d[0];
+                wrow[(size_t)(2 * C + c0) * wstr + t] = dd[0];
+              }
+              if (c1 < C) {
+                wrow[(size_t)c1 * wstr + t] = x[1];
+                wrow[(size_t)(C + c1) * wstr + t] = d[1];
+                wrow[(size_t)(2 * C + c1) * wstr + t] = dd[1];
+              }
             }
           }
         }
@@ -1060,7 +1084,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
 #pragma unroll
     for (int rnd = 0; rnd < RPW / 3; ++rnd) {
 #pragma unroll
-      for (int q = 0; q < 18; ++q) scr[q * 65 + lane] = ps[rnd * 3 + q / 6][q % 6];
+      for (int q = 0; q < 18; ++q) scr[q * 65 + lane] = ps[(rnd * 3 + q / 6) / 2][q % 6][(rnd * 3 + q / 6) % 2];
       wave_lds_sync();
       if (lane < 18) {
         double sum = 0.0;
@@ -1682,9 +1706,16 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   // up to 64 mels: mean-free float32 MFMA.  The eight-group form of it spills its statistics accumulators, so the
   // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tests/diagnostics/margin.py).
-  if (a.dct_pack32 && a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, true>, grid, 512, lds_bytes, s, a);
-  if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false>, grid, 512, lds_bytes, s, a);
-  return launch_one(dysf_mfcc_kernel<512, 8, false>, grid, 512, lds_bytes, s, a);
+  const int full = (a.n_mels == 16 * a.dct_groups) ? a.dct_groups : 0;   // every 16-mel group complete: a fixed-geometry build may apply
+  if (a.dct_pack32 && a.dct_groups <= 4) {
+    if (full == 4 && a.dct_rb == 3) return launch_one(dysf_mfcc_kernel<512, 4, true, 3>, grid, 512, lds_bytes, s, a);
+    if (full == 4 && a.dct_rb == 1) return launch_one(dysf_mfcc_kernel<512, 4, true, 1>, grid, 512, lds_bytes, s, a);
+    return launch_one(dysf_mfcc_kernel<512, 4, true, 0>, grid, 512, lds_bytes, s, a);
+  }
+  if (a.dct_groups <= 4) return launch_one(dysf_mfcc_kernel<512, 4, false, 0>, grid, 512, lds_bytes, s, a);
+  if (full == 8 && a.dct_rb == 3) return launch_one(dysf_mfcc_kernel<512, 8, false, 3>, grid, 512, lds_bytes, s, a);
+  if (full == 8 && a.dct_rb == 1) return launch_one(dysf_mfcc_kernel<512, 8, false, 1>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_mfcc_kernel<512, 8, false, 0>, grid, 512, lds_bytes, s, a);
 }
 int stft_exact_table_floats(int n_fft) {
   switch (n_fft) {
