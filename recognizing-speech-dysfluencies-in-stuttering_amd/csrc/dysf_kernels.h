@@ -90,7 +90,7 @@ constexpr int kStftMiscBase = 32 + 8 * kMelSchedStride;  // kernel A misc area b
 constexpr int kRichDim = 17;                             // rich presets: 7 + 7 contrast statistics, zcr, rms, centroid
 constexpr int kRichFrameLength = 2048;                   // librosa's default frame_length of zero_crossing_rate / rms
 constexpr int kRichSegBytes = 1024 * 16;                 // kernel D: LDS taken from the regions by its segment sums
-constexpr int kMfccCstr = 136;                           // kernel B: LDS row stride of the MFCC chunk (128 columns)
+constexpr int kMfccCstr = 132;                           // kernel B: LDS stride (float2) of a row pair of the MFCC chunk (128 columns)
 constexpr int kPwMaxFrames = 16384;                      // kernel B: longest clip whose statistics follow NumPy's pairwise order
 constexpr int kPwProg = 2 * (kPwMaxFrames / 64 + 2);     // entries of the pairwise-summation program (leaves + adds)
 constexpr int kMfccHead = 144;                           // kernel B: frame-0 features ahead of the DCT operands

@@ -819,7 +819,7 @@ __device__ __forceinline__ float pw_leaf(const float* x, int n, int j, int pass,
 // Mean / variance are one-pass sums of e = x - x[frame 0] (exactly zero for constant rows): float32 per-lane
 // partials across the chunks, one float64 reduction per clip.
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int kBShift = 0;     // float[48][3]: frame-0 features
+constexpr int kBShift = 0;     // float2[24][3]: frame-0 features of the row pairs
 constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-byte aligned)
 
 // RB = 1..3 fixes the geometry at compile time (n_mels == 16 * NG, dct_rb == RB: no mel masks, no per-block branches,
@@ -829,8 +829,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   constexpr int COLS = 16 * NW;
   constexpr int CH = COLS - 16;
-  constexpr int CSTR = kMfccCstr;         // LDS row stride of the MFCC chunk: NW * CSTR is a multiple of 64 (paired ds_read2st64 taps)
-  static_assert((NW * CSTR) % 64 == 0 && 16 % (2 * NW) == 0, "row pairs of the delta pass");
+  // The MFCC chunk sits in LDS as row PAIRS: rows 16p + w and 16p + w + 8 interleaved as float2 per column, pair row
+  // 8p + w, CSTR float2 per pair row (CSTR % 8 == 4: the DCT tile writes of the four lane groups miss each other's
+  // banks).  The delta pass of wave w reads both rows of a pair with one ds_read_b64 per tap.
+  constexpr int CSTR = kMfccCstr;
+  static_assert(NW == 8 && CSTR % 8 == 4, "row pairs of the delta pass");
   constexpr int RPW = (48 + NW - 1) / NW;  // rows per wave (n_mfcc <= 48)
   extern __shared__ __align__(16) float lds[];
   STAMP_INIT;
@@ -872,7 +875,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   if (a.dbg_logmel)
     for (int i = tid; i < T * a.n_mels; i += NT) a.dbg_logmel[i] = lm[(size_t)(i / a.n_mels) * a.lm_stride + (i % a.n_mels)];
 
-  float* kshift = lds + kBShift;
+  f2* kshift = (f2*)(lds + kBShift);   // [pair row][x, d, dd] as row pairs, like the chunk
   double* dct = (double*)(lds + kBDct);
   const float* dct32 = lds + kBDct;               // F32: float A operands, then the float64 row sums of the coefficients
   const int nd = rbs * groups * 256;
@@ -969,7 +972,9 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // f32 C/D map: row = 4 * (lane >> 4) + reg, col = lane & 15
             const int row = rb * 16 + 4 * (lane >> 4) + r;
-            chunk[row * CSTR + wave * 16 + (lane & 15)] = (float)((double)acc[rb][r] + (double)m32 * rowsum[row]);
+            const int ib = 4 * (lane >> 4) + r;  // row within the block: pair row ib & 7, half ib >> 3
+            chunk[((rb * 8 + (ib & 7)) * CSTR + wave * 16 + (lane & 15)) * 2 + (ib >> 3)] =
+                (float)((double)acc[rb][r] + (double)m32 * rowsum[row]);
           }
     } else {
         const double* dp = dct + lane * 4;
@@ -1005,8 +1010,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
         for (int rb = 0; rb < 3; ++rb)
           if (rb < rbs)
   #pragma unroll
-            for (int r = 0; r < 4; ++r)  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
-              chunk[(rb * 16 + (lane >> 4) + 4 * r) * CSTR + wave * 16 + (lane & 15)] = (float)acc[rb][r];
+            for (int r = 0; r < 4; ++r) {  // f64 C/D map: row = (lane >> 4) + 4 * reg, col = lane & 15
+              const int ib = (lane >> 4) + 4 * r;
+              chunk[((rb * 8 + (ib & 7)) * CSTR + wave * 16 + (lane & 15)) * 2 + (ib >> 3)] = (float)acc[rb][r];
+            }
     }
     STAMP(10);  // DCT
     __syncthreads();
@@ -1021,14 +1028,13 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
       const int bc = tc - (t0 - 8);             // column of the delta centre
 #pragma unroll
       for (int p = 0; p < RPW / 2; ++p) {
-        // two rows per pass: c0 and c1 = c0 + NW lie NW * CSTR floats (a multiple of 64) apart, so every tap is one
-        // ds_read2st64_b32 whose register pair feeds packed float32 math directly.  Rows between n_mfcc and the end of
+        // two rows per pass: c0 = 16p + wave and c1 = c0 + 8 are the halves of pair row 8p + wave, so every tap is one
+        // ds_read_b64 whose register pair feeds packed float32 math directly.  Rows between n_mfcc and the end of
         // their 16-row block are zero rows of the DCT pack; they ride along unused.
         const int c0 = wave + 2 * p * NW, c1 = c0 + NW;
         if (c0 < 16 * rbs) {
-          const float* r0 = chunk + c0 * CSTR;
-          const float* r1 = r0 + NW * CSTR;
-          auto ld = [&](int col) { return f2{r0[col], r1[col]}; };
+          const f2* rp = (const f2*)chunk + (p * 8 + wave) * CSTR;
+          auto ld = [&](int col) { return rp[col]; };
           const f2 x = ld(bx);
           f2 d = f2{0.f, 0.f}, dd = f2{0.f, 0.f};
           if (tv) {
@@ -1039,30 +1045,19 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
             dd = (28.f * ((p4 + m4) - x2) + 7.f * ((p3 + m3) - x2) - 8.f * ((p2 + m2) - x2) - 17.f * ((p1 + m1) - x2)) *
                  (1.0f / 462.0f);
           }
-          float* k0 = kshift + c0 * 3;
-          float* k1 = kshift + c1 * 3;
+          f2* ks = kshift + (p * 8 + wave) * 3;
           if (t0 == 0 && sub == 0) {  // shift values = the features of frame 0
-            if (lane == 0) {
-              k0[0] = x[0]; k0[1] = d[0]; k0[2] = dd[0];
-              k1[0] = x[1]; k1[1] = d[1]; k1[2] = dd[1];
-            }
+            if (lane == 0) { ks[0] = x; ks[1] = d; ks[2] = dd; }
             wave_lds_sync();
           }
           if (tv) {
-            const f2 e0 = x - f2{k0[0], k1[0]}, e1 = d - f2{k0[1], k1[1]}, e2 = dd - f2{k0[2], k1[2]};
+            const f2 e0 = x - ks[0], e1 = d - ks[1], e2 = dd - ks[2];
             ps[p][0] += e0; ps[p][1] += e1; ps[p][2] += e2;
             ps[p][3] += e0 * e0; ps[p][4] += e1 * e1; ps[p][5] += e2 * e2;
             if (wrow) {
-              if (c0 < C) {
-                wrow[(size_t)c0 * wstr + t] = x[0];
-                wrow[(size_t)(C + c0) * wstr + t] = d[0];
-                wrow[(size_t)(2 * C + c0) * wstr + t] = dd[0];
-              }
-              if (c1 < C) {
-                wrow[(size_t)c1 * wstr + t] = x[1];
-                wrow[(size_t)(C + c1) * wstr + t] = d[1];
-                wrow[(size_t)(2 * C + c1) * wstr + t] = dd[1];
-              }
+              auto put = [&](int row, float v) { wrow[(size_t)row * wstr + t] = v; };
+              if (c0 < C) { put(c0, x[0]); put(C + c0, d[0]); put(2 * C + c0, dd[0]); }
+              if (c1 < C) { put(c1, x[1]); put(C + c1, d[1]); put(2 * C + c1, dd[1]); }
             }
           }
         }
@@ -1098,7 +1093,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
         if (c < C) {
           const double m1 = tot[lane] / (double)T, m2 = tot[lane + 3] / (double)T;
           const double var = m2 - m1 * m1;
-          prow[j * 2 * C + c] = (float)((double)kshift[c * 3 + j] + m1);
+          prow[j * 2 * C + c] = (float)((double)kshift[((c >> 4) * 8 + (c & 7)) * 3 + j][(c >> 3) & 1] + m1);
           prow[j * 2 * C + C + c] = (float)sqrt(var > 0.0 ? var : 0.0);
         }
       }
