@@ -252,6 +252,36 @@ void    dysf_cnn_destroy(DysfCnn* m);
 int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32_t rows, int32_t cols,
                              const int32_t* d_cols, int64_t row_stride, float* d_logits, void* stream);
 
+/*
+ * Audio cleaning stage ahead of the feature path, clean_audio_and_cache pipeline1.py:126-146:
+ *     y_clean = nr.reduce_noise(y=y, sr=sr)       p1:139  (main.py:655 / main1.py:604 pass prop_decrease=0.8)
+ *     y_clean = librosa.util.normalize(y_clean)   p1:140
+ *     sf.write(out_path, y_clean, sr)             p1:141  (PCM_16)
+ * noisereduce's default non-stationary spectral gate (n_fft 1024, hop 256, 30 000 samples of zero padding), in float64:
+ * scipy.signal.stft -> |X| smoothed by filtfilt([b], [1, b - 1]) -> sigmoid mask -> triangle blur (fftconvolve "same")
+ * -> scipy.signal.istft -> float32; then peak normalisation and libsndfile's clipping PCM_16 conversion.
+ * dysf_clean_create takes nr.reduce_noise's keyword values (defaults: prop_decrease 1.0, time_constant_s 2.0,
+ * freq_mask_smooth_hz 500, time_mask_smooth_ms 50, thresh_n_mult_nonstationary 2, sigmoid_slope_nonstationary 10,
+ * padding 30000).  dysf_clean_batch_dev:
+ *   d_pcm / pcm_type / d_offsets / n_clips / max_samples  as for dysf_extract_batch_dev (offsets on the DEVICE);
+ *   total_samples   offsets[n_clips] (sizes the internal float32 signal when d_denoised is NULL)
+ *   d_denoised      float32, nr.reduce_noise's return value          } each may be NULL; all are indexed like the
+ *   d_normalized    float32, after librosa.util.normalize            } input samples (d_offsets)
+ *   d_pcm16         int16, the samples sf.write stores               }
+ *   d_status        [n_clips] DYSF_OK, DYSF_EMPTY, or DYSF_NONFINITE (the gate produced a non-finite sample, e.g. an
+ *                   all-zero clip: librosa.util.normalize raises there and the reference writes no file)
+ * Clips longer than noisereduce's chunk_size (600 000 samples) are rejected.
+ */
+typedef struct DysfCleaner DysfCleaner;
+const char* dysf_clean_last_error(void);
+int32_t dysf_clean_create(int32_t device, int32_t sr, double prop_decrease, double time_constant_s,
+                          double freq_mask_smooth_hz, double time_mask_smooth_ms, double thresh_n_mult,
+                          double sigmoid_slope, int32_t padding, DysfCleaner** out);
+void    dysf_clean_destroy(DysfCleaner* c);
+int32_t dysf_clean_batch_dev(DysfCleaner* c, const void* d_pcm, int32_t pcm_type, const int64_t* d_offsets, int32_t n_clips,
+                             int64_t max_samples, int64_t total_samples, float* d_denoised, float* d_normalized,
+                             int16_t* d_pcm16, int32_t* d_status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

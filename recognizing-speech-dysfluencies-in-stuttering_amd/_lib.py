@@ -25,6 +25,7 @@ SYMBOLS = (
     "dysf_resampler_last_error", "dysf_resampler_create", "dysf_resampler_destroy", "dysf_resampler_out_len",
     "dysf_resample_batch_dev",
     "dysf_cnn_last_error", "dysf_cnn_create", "dysf_cnn_destroy", "dysf_cnn_forward_dev",
+    "dysf_clean_last_error", "dysf_clean_create", "dysf_clean_destroy", "dysf_clean_batch_dev",
 )
 
 
@@ -109,6 +110,12 @@ def lib():
     L.dysf_cnn_destroy.argtypes = [vp]
     L.dysf_cnn_destroy.restype = None
     L.dysf_cnn_forward_dev.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
+    f64 = ctypes.c_double
+    L.dysf_clean_last_error.restype = ctypes.c_char_p
+    L.dysf_clean_create.argtypes = [i32, i32, f64, f64, f64, f64, f64, f64, i32, ctypes.POINTER(vp)]
+    L.dysf_clean_destroy.argtypes = [vp]
+    L.dysf_clean_destroy.restype = None
+    L.dysf_clean_batch_dev.argtypes = [vp, vp, i32, vp, i32, i64, i64, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)
     if L.dysf_abi_version() != ABI_VERSION:

@@ -19,6 +19,8 @@ Outputs (all under tests/golden/):
   classifier_after.npz     StandardScaler + MLP(128,64) re-fit exactly as pipeline1.py:462-531 does,
                            with the 905x149 feature matrix and expected predict / predict_proba
   forest_after.npz         the RandomForest(200) of pipeline1.py:496 as flat node arrays + expected outputs
+  clean_pin.json           peak / header statistics of all clear_audio/*.wav: what the last two steps of
+                           clean_audio_and_cache (librosa.util.normalize + sf.write PCM_16, p1:140-141) leave behind
 """
 import csv
 import glob
@@ -287,7 +289,35 @@ def svc_fixture():
         expected_decision=svc.decision_function(Xs), evidence=json.dumps(evidence))
 
 
+def clean_pin():
+    """Every WAV in clear_audio/ went through librosa.util.normalize (peak -> 1.0) and python-soundfile's PCM_16 write:
+    record the peaks and the header layout that pin oracle/dysf_clean_oracle.py's normalize + float_to_pcm16."""
+    rec = {"files": 0, "peak_pos_32767": 0, "peak_neg_32768": 0, "other_peaks": [], "header_44_bytes_pcm16_mono_16k": 0}
+    for f in sorted(glob.glob(os.path.join(REF, "clear_audio", "*.wav"))):
+        b = open(f, "rb").read()
+        d = np.frombuffer(b[44:], dtype="<i2")
+        rec["files"] += 1
+        hdr_ok = (b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[16:36] == np.array([16], "<u4").tobytes() +
+                  np.array([1, 1], "<u2").tobytes() + np.array([16000, 32000], "<u4").tobytes() + np.array([2, 16], "<u2").tobytes()
+                  and b[36:40] == b"data" and int(np.frombuffer(b[40:44], "<u4")[0]) == len(b) - 44
+                  and int(np.frombuffer(b[4:8], "<u4")[0]) == len(b) - 8)
+        rec["header_44_bytes_pcm16_mono_16k"] += int(hdr_ok)
+        mx, mn = int(d.max()), int(d.min())
+        if mx == 32767 and mn > -32768:
+            rec["peak_pos_32767"] += 1
+        elif mn == -32768 and mx < 32767:
+            rec["peak_neg_32768"] += 1
+        else:
+            rec["other_peaks"].append([os.path.basename(f), mx, mn])
+    with open(os.path.join(HERE, "clean_pin.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print("clean_pin:", {k: (v if not isinstance(v, list) else len(v)) for k, v in rec.items()})
+
+
 if __name__ == "__main__":
+    if "--clean-pin-only" in sys.argv:
+        clean_pin()
+        sys.exit(0)
     if "--forest-only" in sys.argv:
         forest_fixture()
         sys.exit(0)
@@ -303,3 +333,4 @@ if __name__ == "__main__":
     classifier_fixture()
     forest_fixture()
     svc_fixture()
+    clean_pin()

@@ -870,3 +870,92 @@ def test_lane_executor_large_batch_equals_single_call(ex512):
     torch.cuda.synchronize()
     for k in ("status", "pooled", "frames"):
         assert torch.equal(got[k], want[k]), k
+
+
+# ---------------------------------------------------------------------------------------------
+# Cleaning stage (pipeline1.py:126-146): dysf_clean_batch_dev against oracle/dysf_clean_oracle.py.
+# The oracle's gate is parity-unpinned (noisereduce absent, see its header); normalise + PCM_16 are pinned on reference data.
+from oracle import dysf_clean_oracle as CO  # noqa: E402
+
+
+def _noisy(i, n):
+    rng = np.random.default_rng(100 + i)
+    y = O.pcm16_to_float(synth_clip(i, n=n))
+    return (y * np.float32(0.5) + np.float32(0.01) * rng.standard_normal(n).astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("prop", [1.0, 0.8], ids=["p1_default", "main_prop0.8"])
+def test_cleaning_stage_matches_oracle(prop, golden_dir):
+    """nr.reduce_noise -> librosa.util.normalize -> PCM_16 (p1:139-141; m:655 with prop_decrease 0.8): the int16 samples
+    the reference would write, bit for bit, on a ragged batch of float32 and int16-derived clips."""
+    clips = [_noisy(0, 48000), _noisy(1, 16001), _noisy(2, 1000), _noisy(5, 255), _noisy(7, 70000)]
+    clips.append(O.pcm16_to_float(next(iter(_pairs(golden_dir)))[1]))       # a reference clear_audio clip, cleaned again
+    cl = rsd_amd.AudioCleaner(sr=16000, device=0, prop_decrease=prop)
+    res = cl.clean_batch(clips, denoised=True, normalized=True, pcm16=True)
+    assert (res["status"] == 0).all()
+    mism = 0
+    for y, den, nrm, q in zip(clips, res["denoised"], res["normalized"], res["pcm16"]):
+        ref = CO.reduce_noise(y, 16000, prop)
+        assert den.dtype == np.float32 and den.shape == ref.shape
+        assert np.abs(den.astype(np.float64) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-30)
+        ref_n = CO.normalize(ref)
+        assert np.abs(nrm - ref_n).max() <= 2e-6
+        assert np.abs(nrm).max() == 1.0
+        ref_q = CO.float_to_pcm16(ref_n)
+        assert q.dtype == np.int16
+        d = np.abs(q.astype(np.int32) - ref_q.astype(np.int32))
+        assert d.max() <= 1                      # float64 round-off may move a sample across a rounding boundary
+        mism += int((d != 0).sum())
+        # the integer step itself is exact: the oracle's normalise + PCM_16 applied to OUR float32 signal
+        assert (q == CO.float_to_pcm16(CO.normalize(den))).all()
+        assert (nrm == CO.normalize(den)).all()
+    assert mism <= 3, mism                       # of ~190 000 samples
+    cl.close()
+
+
+def test_cleaning_int16_input_equals_float32_input():
+    y16 = synth_clip(9, n=30000)
+    a = rsd_amd.get_cleaner(16000, 0).clean_batch([y16], pcm16=True, denoised=True)
+    b = rsd_amd.get_cleaner(16000, 0).clean_batch([O.pcm16_to_float(y16)], pcm16=True, denoised=True)
+    assert (a["pcm16"][0] == b["pcm16"][0]).all() and (a["denoised"][0] == b["denoised"][0]).all()
+    one = rsd_amd.reduce_noise(O.pcm16_to_float(y16), 16000)
+    assert one.dtype == np.float32 and (one == a["denoised"][0]).all()
+    with pytest.raises(NotImplementedError):
+        rsd_amd.reduce_noise(O.pcm16_to_float(y16), 16000, stationary=True)
+
+
+def test_cleaning_error_convention_and_batch_independence():
+    """An all-zero clip makes the gate divide 0 by 0: librosa.util.normalize raises on the NaNs and the reference writes
+    no file (p1:143-145).  Here: status NONFINITE, zero outputs, and the neighbours in the batch are untouched."""
+    good = _noisy(3, 20000)
+    res = rsd_amd.get_cleaner(16000, 0).clean_batch([good, np.zeros(5000, np.float32), np.zeros(0, np.float32), good],
+                                                    pcm16=True, normalized=True)
+    assert res["status"].tolist() == [0, 2, 3, 0]          # DYSF_OK, DYSF_NONFINITE, DYSF_EMPTY, DYSF_OK
+    assert (res["pcm16"][1] == 0).all() and len(res["pcm16"][2]) == 0
+    alone = rsd_amd.get_cleaner(16000, 0).clean_batch([good], pcm16=True)
+    assert (res["pcm16"][0] == alone["pcm16"][0]).all() and (res["pcm16"][3] == alone["pcm16"][0]).all()
+    with pytest.raises(ValueError):
+        CO.normalize(CO.reduce_noise(np.zeros(5000, np.float32), 16000))    # the reference's failure, same clip
+
+
+def test_clean_audio_and_cache_end_to_end(tmp_path):
+    """pipeline1.py:126-146 as one call: WAV in -> clear_dir/<stem>.wav (memoised) -> the feature path reads it back."""
+    y = _noisy(4, 40000)
+    src = tmp_path / "raw clip (1).wav"
+    rsd_amd.write_wav_pcm16(str(src), CO.float_to_pcm16(y), 16000)
+    clear = tmp_path / "clear_audio"
+    out = rsd_amd.clean_audio_and_cache(str(src), clear_dir=str(clear))
+    assert out == os.path.normpath(str(clear / "raw clip (1).wav")) and os.path.exists(out)
+    pcm, sr = O.read_wav_pcm16(out)
+    y_in, _ = rsd_amd.load_audio(str(src))
+    assert sr == 16000 and (pcm == CO.clean_audio(y_in, 16000)).mean() > 0.9999
+    assert max(pcm.max(), -int(pcm.min())) in (32767, 32768)
+    stamp = os.path.getmtime(out)
+    assert rsd_amd.clean_audio_and_cache(str(src), clear_dir=str(clear)) == out and os.path.getmtime(out) == stamp
+    y2, sr2 = rsd_amd.load_audio(out)
+    feats = rsd_amd.extract_features(y2, sr2)
+    assert feats.shape == (149,) and np.abs(feats - O.extract_features(O.pcm16_to_float(pcm), 16000)).max() <= 1e-4
+    silent = tmp_path / "silent.wav"
+    rsd_amd.write_wav_pcm16(str(silent), np.zeros(3000, np.int16), 16000)
+    assert rsd_amd.clean_audio_and_cache(str(silent), clear_dir=str(clear)) is None
+    assert rsd_amd.clean_audio_and_cache(str(tmp_path / "missing.wav"), clear_dir=str(clear)) is None

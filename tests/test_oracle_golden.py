@@ -144,3 +144,101 @@ def test_svc_restatement_reproduces_sklearn(golden_dir):
     assert np.abs(dec - z["expected_decision"]).max() < 1e-9
     assert (O.svc_predict(dec, 3) == z["expected_pred"]).all()
     assert np.abs(O.svc_predict_proba(dec, z["prob_a"], z["prob_b"], 3) - z["expected_proba"]).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# Cleaning stage (pipeline1.py:126-146): oracle/dysf_clean_oracle.py
+from oracle import dysf_clean_oracle as CO  # noqa: E402
+
+
+def test_reference_clean_wavs_pin_normalise_and_pcm16(golden_dir):
+    """librosa.util.normalize + sf.write (p1:140-141) leave every clear_audio/*.wav with a peak of exactly +32767 or
+    -32768 (scale 32768, clipped): the committed record of all 892 files, the committed pairs, and the oracle's rule."""
+    rec = json.load(open(os.path.join(golden_dir, "clean_pin.json")))
+    assert rec["files"] == 892 and rec["other_peaks"] == [] and rec["peak_pos_32767"] + rec["peak_neg_32768"] == 892
+    assert rec["peak_neg_32768"] > 0 and rec["peak_pos_32767"] > 0   # a symmetric 32767 scale could never give -32768
+    assert rec["header_44_bytes_pcm16_mono_16k"] == 892
+    for e, pcm, sr, _ in _pairs(golden_dir):
+        assert (pcm.max() == 32767) != (pcm.min() == -32768), e
+    rng = np.random.default_rng(3)
+    for sign in (1.0, -1.0):
+        y = rng.standard_normal(4000).astype(np.float32) * np.float32(0.01)
+        y[1234] = np.float32(sign * 0.37)
+        q = CO.float_to_pcm16(CO.normalize(y))
+        assert (q.max(), q.min())[sign < 0] == (32767 if sign > 0 else -32768)
+        assert np.abs(q.astype(np.int32)).max() == (32767 if sign > 0 else 32768)
+    # round half to even, clipping on both sides
+    got = CO.float_to_pcm16(np.array([0.5 / 32768, 1.5 / 32768, -0.5 / 32768, -2.5 / 32768, 0.99999, 1.0, -1.0, 1.5, -1.5], np.float32))
+    assert got.tolist() == [0, 2, 0, -2, 32767, 32767, -32768, 32767, -32768]
+    with pytest.raises(ValueError):
+        CO.normalize(np.array([0.0, np.nan], np.float32))
+    assert (CO.normalize(np.zeros(8, np.float32)) == 0).all()    # a peak below tiny divides by 1
+
+
+def _explicit_gate(y, sr, prop=1.0):
+    """The gate written out step by step (what the HIP kernels do), against the SciPy calls the oracle makes."""
+    n, P, nfft, hop = len(y), CO.PADDING, CO.N_FFT, CO.N_FFT // 4
+    chunk = np.zeros(n + 2 * P)
+    chunk[P:P + n] = y
+    ext = np.concatenate([np.zeros(nfft // 2), chunk, np.zeros(nfft // 2)])
+    T = (len(ext) - nfft) // hop + 1
+    win = scipy.signal.get_window("hann", nfft)
+    X = np.fft.rfft(np.stack([ext[t * hop:t * hop + nfft] for t in range(T)]) * win, axis=1) / win.sum()
+    A = np.abs(X)
+    b = CO.time_smoothing_coefficient(sr, hop)
+    yf = np.empty_like(A)
+    yf[0] = A[0]
+    for t in range(1, T):
+        yf[t] = b * A[t] + (1 - b) * yf[t - 1]
+    yb = np.empty_like(A)
+    yb[T - 1] = yf[T - 1]
+    for t in range(T - 2, -1, -1):
+        yb[t] = b * yf[t] + (1 - b) * yb[t + 1]
+    m = 1 / (1 + np.exp(-((A - yb) / yb - 2) * 10))
+    ngf, ngt = CO.mask_smoothing_sizes(sr, nfft, hop)
+    filt = CO.smoothing_filter(ngf, ngt)          # [freq taps, time taps]
+    mp = np.pad(m, ((ngt, ngt), (ngf, ngf)))
+    ms = np.zeros_like(m)
+    for dt in range(filt.shape[1]):
+        for df in range(filt.shape[0]):
+            ms += filt[df, dt] * mp[dt:dt + T, df:df + m.shape[1]]
+    Xd = X * (ms * prop + (1 - prop))
+    xs = np.fft.irfft(Xd, n=nfft, axis=1) * win.sum()
+    x = np.zeros(nfft + (T - 1) * hop)
+    norm = np.zeros_like(x)
+    for t in range(T):
+        x[t * hop:t * hop + nfft] += xs[t] * win
+        norm[t * hop:t * hop + nfft] += win ** 2
+    x /= np.where(norm > 1e-10, norm, 1.0)
+    x = x[nfft // 2:-(nfft // 2)]
+    o = np.zeros(len(chunk))
+    o[:len(x)] = x[:len(chunk)]
+    return o[P:P + n].astype(y.dtype)
+
+
+@pytest.mark.parametrize("prop", [1.0, 0.8])
+def test_clean_oracle_equals_the_written_out_gate(prop):
+    rng = np.random.default_rng(11)
+    t = np.arange(9000) / 16000.0
+    y = (0.3 * np.sin(2 * np.pi * 220 * t) * (np.sin(2 * np.pi * 3 * t) > 0) + 0.02 * rng.standard_normal(len(t))).astype(np.float32)
+    ref = CO.reduce_noise(y, 16000, prop)
+    exp = _explicit_gate(y, 16000, prop)
+    assert ref.dtype == np.float32 and ref.shape == y.shape
+    assert np.abs(ref.astype(np.float64) - exp).max() <= 2e-7 * np.abs(ref).max()
+    assert (CO.float_to_pcm16(CO.normalize(ref)) != CO.float_to_pcm16(CO.normalize(exp))).sum() <= 2
+    assert np.sum(ref.astype(np.float64) ** 2) < 0.9 * np.sum(y.astype(np.float64) ** 2)   # the gate removes energy
+    sizes = CO.mask_smoothing_sizes(16000, 1024, 256)
+    assert sizes == (16, 3) and CO.smoothing_filter(*sizes).shape == (33, 7)
+    assert abs(CO.time_smoothing_coefficient(16000, 256) - 0.00796803) < 1e-7
+
+
+def test_write_wav_pcm16_reproduces_the_reference_files_byte_for_byte(golden_dir, tmp_path):
+    """sf.write's PCM_16 container (p1:141): our writer gives back the committed reference WAVs bit for bit."""
+    from rsd_amd.cleaning import write_wav_pcm16
+    n = 0
+    for e, pcm, sr, _ in _pairs(golden_dir):
+        out = tmp_path / "w.wav"
+        write_wav_pcm16(str(out), pcm, sr)
+        assert out.read_bytes() == open(os.path.join(golden_dir, "ref_pairs", e["id"] + ".wav"), "rb").read(), e
+        n += 1
+    assert n == 17
