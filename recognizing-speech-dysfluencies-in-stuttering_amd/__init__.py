@@ -12,6 +12,7 @@ from .features import (CACHE_DIR, FeatureExtractor, HostTables, cached_extract_f
                        load_audio, load_cache, repetition_stats_from_text, save_cache)
 from .metrics import audio_metrics_batch, high_freq_energy_ratio, snr_db, spectral_flatness_mean
 from .cleaning import CLEAR_DIR, AudioCleaner, clean_audio_and_cache, get_cleaner, reduce_noise, write_wav_pcm16
+from .preprocess import cached_extract_features_batch, list_audio_files, preprocess_files, write_per_file_analysis
 
 __all__ = [
     "DysfError", "FeatureParams", "REFERENCE_149", "BENCH_512", "MAIN_286", "TARGET_SR", "CACHE_DIR", "FeatureExtractor",
@@ -19,4 +20,5 @@ __all__ = [
     "extract_audio_features", "extract_text_features", "extract_features", "cached_extract_features",
     "repetition_stats_from_text", "snr_db", "spectral_flatness_mean", "high_freq_energy_ratio", "audio_metrics_batch",
     "CLEAR_DIR", "AudioCleaner", "get_cleaner", "reduce_noise", "clean_audio_and_cache", "write_wav_pcm16",
+    "list_audio_files", "preprocess_files", "write_per_file_analysis", "cached_extract_features_batch",
 ]

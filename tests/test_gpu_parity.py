@@ -959,3 +959,66 @@ def test_clean_audio_and_cache_end_to_end(tmp_path):
     rsd_amd.write_wav_pcm16(str(silent), np.zeros(3000, np.int16), 16000)
     assert rsd_amd.clean_audio_and_cache(str(silent), clear_dir=str(clear)) is None
     assert rsd_amd.clean_audio_and_cache(str(tmp_path / "missing.wav"), clear_dir=str(clear)) is None
+
+
+def test_preprocess_loop_and_feature_caching_as_batched_passes(golden_dir, tmp_path):
+    """pipeline1.py:371-417 + 447-456 through rsd_amd.preprocess_files / cached_extract_features_batch: labels from the folder,
+    metrics before / after, clear_dir memoisation (a reference clear_audio file already present is reused, so its `after`
+    columns must equal the reference's per_file_analysis.csv), fall-back to the original when cleaning fails, and the cache
+    files of the feature loop equal to the reference's committed vectors."""
+    idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
+    root, clear, cache = tmp_path / "segrigated_samples", tmp_path / "clear_audio", tmp_path / "cache_features"
+    (root / "word repetition").mkdir(parents=True); (root / "Prolongatio sample").mkdir(); clear.mkdir()
+    # (a) two noisy synthetic "raw" files; (b) three reference stems whose cleaned WAV already sits in clear_dir; (c) silence
+    rsd_amd.write_wav_pcm16(str(root / "word repetition" / "w1.wav"), CO.float_to_pcm16(_noisy(11, 30000)), 16000)
+    rsd_amd.write_wav_pcm16(str(root / "word repetition" / "w2 (1).wav"), CO.float_to_pcm16(_noisy(12, 21000)), 16000)
+    rsd_amd.write_wav_pcm16(str(root / "word repetition" / "silent.wav"), np.zeros(4000, np.int16), 16000)
+    (root / "word repetition" / "notes.txt").write_text("not audio")
+    (root / "word repetition" / "broken.wav").write_bytes(b"RIFFxxxx")
+    ref = {}
+    for (cid, pcm, sr, gold), e in list(zip(_pairs(golden_dir), idx))[:3]:
+        stem = e["reference_stem"]
+        rsd_amd.write_wav_pcm16(str(root / "Prolongatio sample" / f"{stem}.wav"), CO.float_to_pcm16(_noisy(20 + len(ref), len(pcm))), 16000)
+        rsd_amd.write_wav_pcm16(str(clear / f"{stem}.wav"), pcm, 16000)      # the reference's own cleaned file
+        ref[f"{stem}.wav"] = (e["metrics_after"], gold, pcm)
+    files = rsd_amd.list_audio_files(str(root))
+    assert len(files) == 7 and all(f.endswith(".wav") for f in files) and files == sorted(files)
+    res = rsd_amd.preprocess_files(files, clear_dir=str(clear), batch=4)
+    rows = {r["file"]: r for r in res["per_file"]}
+    assert res["skipped"] == 1 and len(rows) == 6 and "broken.wav" not in rows
+    assert rows["w1.wav"]["label"] == "word repetition" and abs(rows["w1.wav"]["duration_sec"] - 30000 / 16000) < 1e-12
+    for name, (want, gold, pcm) in ref.items():          # memoised reference files: the CSV's `after` columns
+        r = rows[name]
+        assert r["label"] == "Prolongatio sample"
+        assert abs(r["snr_after_db"] - want[0]) <= 2e-4 and abs(r["spectral_flatness_after"] - want[1]) <= 5e-4 * want[1]
+        assert abs(r["hf_energy_ratio_after"] - want[2]) <= 2e-5 * want[2]
+        assert (O.read_wav_pcm16(str(clear / name))[0] == pcm).all()          # not overwritten
+    # freshly cleaned files: written, equal to the oracle's samples, and the `after` metrics are those of the written file
+    for name in ("w1.wav", "w2 (1).wav"):
+        y_in, _ = rsd_amd.load_audio(str(root / "word repetition" / name))
+        q, _ = O.read_wav_pcm16(str(clear / name))
+        assert (q != CO.clean_audio(y_in, 16000)).sum() <= 1
+        m = rsd_amd.audio_metrics_batch([q], 16000)[0]
+        assert abs(rows[name]["snr_after_db"] - m[0]) <= 1e-4 and rows[name]["snr_after_db"] > rows[name]["snr_before_db"]
+        b = rsd_amd.audio_metrics_batch([O.read_wav_pcm16(str(root / "word repetition" / name))[0]], 16000)[0]
+        assert abs(rows[name]["snr_before_db"] - b[0]) <= 1e-4 and abs(rows[name]["hf_energy_ratio_before"] - b[2]) <= 1e-6
+    # cleaning failed for the silent file (non-finite gate output): the original is used, as p1:386-388 does
+    assert not (clear / "silent.wav").exists()
+    assert res["clean_paths"][res["raw_paths"].index(str(root / "word repetition" / "silent.wav"))].endswith(os.path.join("word repetition", "silent.wav"))
+    rsd_amd.write_per_file_analysis(res["per_file"], str(tmp_path / "per_file_analysis.csv"))
+    import csv as _csv
+    back = list(_csv.DictReader(open(tmp_path / "per_file_analysis.csv")))
+    assert len(back) == 6 and float(back[0]["snr_after_db"]) == res["per_file"][0]["snr_after_db"] and back[0]["transcript"] == ""
+    # feature loop p1:447-456
+    Xa = rsd_amd.cached_extract_features_batch(res["clean_paths"], "clean", cache_dir=str(cache), batch=4)
+    Xb = rsd_amd.cached_extract_features_batch(res["raw_paths"], "raw", cache_dir=str(cache), batch=4)
+    assert Xa.shape == Xb.shape == (6, 149) and Xa.dtype == np.float32
+    for i, p in enumerate(res["clean_paths"]):
+        name = os.path.basename(p)
+        blob = open(cache / (name.rsplit(".", 1)[0] + "_clean_feats.npy"), "rb").read()
+        assert len(blob) == 724 and (np.load(cache / (name.rsplit(".", 1)[0] + "_clean_feats.npy")) == Xa[i]).all()
+        if name in ref:
+            assert np.abs(Xa[i] - ref[name][1]).max() <= 1e-4          # the reference's cache_features vector
+        assert (Xa[i] == rsd_amd.cached_extract_features(p, "", "clean", cache_dir=str(cache))).all()
+    assert (Xa[res["raw_paths"].index(str(root / "word repetition" / "silent.wav"))][:144] == O.extract_features(np.zeros(4000, np.float32), 16000)[:144]).all()
+    assert (rsd_amd.cached_extract_features_batch(res["clean_paths"], "clean", cache_dir=str(cache)) == Xa).all()   # second run: cache hits
