@@ -268,9 +268,11 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
  *   d_denoised      float32, nr.reduce_noise's return value          } each may be NULL; all are indexed like the
  *   d_normalized    float32, after librosa.util.normalize            } input samples (d_offsets)
  *   d_pcm16         int16, the samples sf.write stores               }
- *   d_status        [n_clips] DYSF_OK, DYSF_EMPTY, or DYSF_NONFINITE (the gate produced a non-finite sample, e.g. an
- *                   all-zero clip: librosa.util.normalize raises there and the reference writes no file)
- * Clips longer than noisereduce's chunk_size (600 000 samples) are rejected.
+ *   d_status        [n_clips] DYSF_OK, DYSF_EMPTY, DYSF_TOO_LONG (the clip has more samples than max_samples: left
+ *                   untouched) or DYSF_NONFINITE (the gate produced a non-finite sample, e.g. an all-zero clip:
+ *                   librosa.util.normalize raises there and the reference writes no file)
+ * max_samples beyond noisereduce's chunk_size (600 000 samples) is rejected.  A handle owns its workspaces: use one
+ * handle per stream (work queued on one stream is ordered).
  */
 typedef struct DysfCleaner DysfCleaner;
 const char* dysf_clean_last_error(void);

@@ -42,6 +42,7 @@ struct CleanDev {
   int clip0;                 // first clip of this sub-batch
   int padding;               // zeros either side (30 000)
   int t_max;                 // frame stride of the workspaces
+  long long max_samples;     // the caller's bound on a clip's length: longer clips are rejected (DYSF_TOO_LONG), not processed
   double b;                  // one-pole coefficient of the time smoothing
   double shift, slope;       // sigmoid(x, shift, slope): shift = -thresh_n_mult_nonstationary
   double prop;               // prop_decrease
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void clean_stft_kernel(CleanDev c) {
   __shared__ double2 buf[2][kN];
   const int lc = blockIdx.y, clip = c.clip0 + lc, t = blockIdx.x, tid = threadIdx.x;
   const long long off = c.offsets[clip], n = c.offsets[clip + 1] - off;
-  if (n <= 0 || t >= frames_of(n, c.padding)) return;
+  if (n <= 0 || n > c.max_samples || t >= frames_of(n, c.padding)) return;
   for (int j = tid; j < kN; j += 256) {
     const long long s = (long long)t * kHop + j - kN / 2 - c.padding;   // sample of the clip under tap j
     double v = 0.0;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void clean_stft_kernel(CleanDev c) {
 __global__ __launch_bounds__(64) void clean_gate_kernel(CleanDev c) {
   const int lc = blockIdx.y, clip = c.clip0 + lc, f = blockIdx.x * 64 + threadIdx.x;
   const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || f >= kBins) return;
+  if (n <= 0 || n > c.max_samples || f >= kBins) return;
   const int T = frames_of(n, c.padding);
   const double2* sp = c.spec + (size_t)lc * c.t_max * kBins + f;
   double* sm = c.smooth + (size_t)lc * c.t_max * kBins + f;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) void clean_gate_kernel(CleanDev c) {
 __global__ __launch_bounds__(256) void clean_blur_freq_kernel(CleanDev c) {
   const int lc = blockIdx.z, clip = c.clip0 + lc, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
   const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || f >= kBins || t >= frames_of(n, c.padding)) return;
+  if (n <= 0 || n > c.max_samples || f >= kBins || t >= frames_of(n, c.padding)) return;
   const double* mk = c.mask + ((size_t)lc * c.t_max + t) * kBins;
   const int hf = c.nf / 2;
   double row = 0.0;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void clean_blur_freq_kernel(CleanDev c) {
 __global__ __launch_bounds__(256) void clean_blur_time_kernel(CleanDev c) {
   const int lc = blockIdx.z, clip = c.clip0 + lc, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
   const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || f >= kBins) return;
+  if (n <= 0 || n > c.max_samples || f >= kBins) return;
   const int T = frames_of(n, c.padding);
   if (t >= T) return;
   const double* rows = c.smooth + (size_t)lc * c.t_max * kBins + f;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void clean_istft_kernel(CleanDev c) {
   __shared__ double2 buf[2][kN];
   const int lc = blockIdx.y, clip = c.clip0 + lc, t = blockIdx.x, tid = threadIdx.x;
   const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || t >= frames_of(n, c.padding)) return;
+  if (n <= 0 || n > c.max_samples || t >= frames_of(n, c.padding)) return;
   const double2* src = c.spec + ((size_t)lc * c.t_max + t) * kBins;
   for (int f = tid; f < kBins; f += 256) {
     double2 z = src[f];
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void clean_ola_kernel(CleanDev c) {
   const int lc = blockIdx.y, clip = c.clip0 + lc;
   const long long off = c.offsets[clip], n = c.offsets[clip + 1] - off;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || n > c.max_samples) return;
   const int T = frames_of(n, c.padding);
   const long long q = i + c.padding;          // index in the padded chunk
   float out = 0.f;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void clean_quant_kernel(CleanDev c) {
   const int clip = c.clip0 + blockIdx.y;
   const long long off = c.offsets[clip], n = c.offsets[clip + 1] - off;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || n > c.max_samples) return;
   const bool bad = c.status[clip] != DYSF_OK;   // librosa raises on non-finite input: the reference writes no file
   double peak = (double)__uint_as_float(c.peak[clip]);
   if (peak < 1.1754943508222875e-38) peak = 1.0;
@@ -247,7 +248,8 @@ __global__ void clean_init_kernel(CleanDev c, int n_sub) {
   if (i >= n_sub) return;
   const int clip = c.clip0 + i;
   c.peak[clip] = 0u;
-  c.status[clip] = (c.offsets[clip + 1] - c.offsets[clip] > 0) ? DYSF_OK : DYSF_EMPTY;
+  const long long n = c.offsets[clip + 1] - c.offsets[clip];
+  c.status[clip] = n <= 0 ? DYSF_EMPTY : (n > c.max_samples ? DYSF_TOO_LONG : DYSF_OK);
 }
 
 struct Buf {
@@ -344,7 +346,7 @@ void dysf_clean_destroy(DysfCleaner* c) {
 /* pipeline1.py:139-141 for a batch of clips resident in device memory.  Any of the three outputs may be null:
    d_denoised (float32, nr.reduce_noise's return value), d_normalized (float32, after librosa.util.normalize),
    d_pcm16 (int16, the samples sf.write stores); all are indexed like the input (d_offsets).  d_status[n_clips]:
-   DYSF_OK, DYSF_EMPTY (no samples: outputs untouched) or DYSF_NONFINITE (the gate produced a non-finite sample --
+   DYSF_OK, DYSF_EMPTY (no samples: outputs untouched), DYSF_TOO_LONG (longer than max_samples: outputs untouched) or DYSF_NONFINITE (the gate produced a non-finite sample --
    librosa.util.normalize raises there and the reference writes no file; the normalised / PCM outputs are zero). */
 int32_t dysf_clean_batch_dev(DysfCleaner* c, const void* d_pcm, int32_t pcm_type, const int64_t* d_offsets, int32_t n_clips,
                              int64_t max_samples, int64_t total_samples, float* d_denoised, float* d_normalized,
@@ -364,7 +366,7 @@ int32_t dysf_clean_batch_dev(DysfCleaner* c, const void* d_pcm, int32_t pcm_type
     g_clerr = "out of device memory for the cleaning workspace"; return DYSF_E_NOMEM;
   }
   CleanDev d{};
-  d.pcm = d_pcm; d.offsets = (const long long*)d_offsets; d.pcm_type = pcm_type; d.padding = c->padding; d.t_max = t_max;
+  d.pcm = d_pcm; d.offsets = (const long long*)d_offsets; d.pcm_type = pcm_type; d.padding = c->padding; d.t_max = t_max; d.max_samples = max_samples;
   d.b = c->b; d.shift = c->shift; d.slope = c->slope; d.prop = c->prop; d.nf = c->nf; d.nt = c->nt; d.inv_tot = c->inv_tot;
   d.tw = c->d_tw; d.win = c->d_win; d.wf = c->d_wf; d.wt = c->d_wt;
   d.spec = (double2*)c->spec.p; d.smooth = (double*)c->smooth.p; d.mask = (double*)c->mask.p; d.seg = (double*)c->seg.p;

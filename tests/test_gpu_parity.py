@@ -936,6 +936,15 @@ def test_cleaning_error_convention_and_batch_independence():
     assert (res["pcm16"][0] == alone["pcm16"][0]).all() and (res["pcm16"][3] == alone["pcm16"][0]).all()
     with pytest.raises(ValueError):
         CO.normalize(CO.reduce_noise(np.zeros(5000, np.float32), 16000))    # the reference's failure, same clip
+    # device entry point with a max_samples below a clip's length: that clip is rejected (status 4), the others are cleaned
+    import torch
+    short = _noisy(6, 6000)
+    pcm = torch.from_numpy(np.concatenate([short, good])).cuda()
+    off = torch.tensor([0, len(short), len(short) + len(good)], dtype=torch.int64, device="cuda")
+    r2 = rsd_amd.get_cleaner(16000, 0).clean_batch_device(pcm, off, 8000, pcm16=True)
+    assert r2["status"].cpu().tolist() == [0, 4]
+    q = r2["pcm16"].cpu().numpy()
+    assert (q[:len(short)] == rsd_amd.get_cleaner(16000, 0).clean_batch([short], pcm16=True)["pcm16"][0]).all() and (q[len(short):] == 0).all()
 
 
 def test_clean_audio_and_cache_end_to_end(tmp_path):
