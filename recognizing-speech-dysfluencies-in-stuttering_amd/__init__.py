@@ -13,6 +13,7 @@ from .features import (CACHE_DIR, FeatureExtractor, HostTables, cached_extract_f
 from .metrics import audio_metrics_batch, high_freq_energy_ratio, snr_db, spectral_flatness_mean
 from .cleaning import CLEAR_DIR, AudioCleaner, clean_audio_and_cache, get_cleaner, reduce_noise, write_wav_pcm16
 from .preprocess import cached_extract_features_batch, list_audio_files, preprocess_files, write_per_file_analysis
+from .predictor import DeployedPredictor, clean_audio_and_cache_main1
 
 __all__ = [
     "DysfError", "FeatureParams", "REFERENCE_149", "BENCH_512", "MAIN_286", "TARGET_SR", "CACHE_DIR", "FeatureExtractor",
@@ -21,4 +22,5 @@ __all__ = [
     "repetition_stats_from_text", "snr_db", "spectral_flatness_mean", "high_freq_energy_ratio", "audio_metrics_batch",
     "CLEAR_DIR", "AudioCleaner", "get_cleaner", "reduce_noise", "clean_audio_and_cache", "write_wav_pcm16",
     "list_audio_files", "preprocess_files", "write_per_file_analysis", "cached_extract_features_batch",
+    "DeployedPredictor", "clean_audio_and_cache_main1",
 ]

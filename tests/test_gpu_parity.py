@@ -1031,3 +1031,50 @@ def test_preprocess_loop_and_feature_caching_as_batched_passes(golden_dir, tmp_p
         assert (Xa[i] == rsd_amd.cached_extract_features(p, "", "clean", cache_dir=str(cache))).all()
     assert (Xa[res["raw_paths"].index(str(root / "word repetition" / "silent.wav"))][:144] == O.extract_features(np.zeros(4000, np.float32), 16000)[:144]).all()
     assert (rsd_amd.cached_extract_features_batch(res["clean_paths"], "clean", cache_dir=str(cache)) == Xa).all()   # second run: cache hits
+
+
+def test_deployed_predictor_object_with_cleaning(golden_dir, tmp_path):
+    """main1.py:949-990 through rsd_amd.DeployedPredictor: (i) an upload whose cleaned WAV already sits in clear_audio/ (the
+    reference's own file) must give scikit-learn's label and probabilities for the reference's cached vector; (ii) a fresh
+    noisy upload is cleaned with main1's prop_decrease=0.8, memoised, and classified like the oracle's chain says;
+    (iii) silence: cleaning fails, the input itself is classified (m1:609 returns in_path); (iv) unreadable input."""
+    from rsd_amd.classifier import RandomForestHead
+    c = np.load(os.path.join(golden_dir, "classifier_after.npz"), allow_pickle=False)
+    f = np.load(os.path.join(golden_dir, "forest_after.npz"), allow_pickle=False)
+    classes = [str(x) for x in c["classes"]]
+    rf = RandomForestHead.from_npz(os.path.join(golden_dir, "forest_after.npz"), classes=classes)
+    clear = tmp_path / "clear_audio"
+    clear.mkdir()
+    dp = rsd_amd.DeployedPredictor(rf, classes, clear_dir=str(clear))
+    idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
+    for (cid, pcm, sr, gold), e in list(zip(_pairs(golden_dir), idx))[:4]:
+        up = tmp_path / f"{e['reference_stem']}.wav"                       # the "upload": any audio with this stem ...
+        rsd_amd.write_wav_pcm16(str(up), CO.float_to_pcm16(_noisy(30, len(pcm))), 16000)
+        rsd_amd.write_wav_pcm16(str(clear / up.name), pcm, 16000)           # ... whose cleaned file the reference already has
+        rows = np.nonzero((c["X"] == gold[None, :]).all(axis=1))[0]
+        label, prob = dp.predict_file(str(up))
+        assert label == classes[int(f["expected_pred"][rows[0]])], (cid, label)
+        assert max(abs(prob[k] - f["expected_proba"][rows[0]][i]) for i, k in enumerate(classes)) <= 0.0051
+        assert abs(sum(prob.values()) - 1.0) < 1e-6
+    # (ii) fresh upload
+    y = _noisy(31, 26000)
+    up = tmp_path / "fresh upload.wav"
+    rsd_amd.write_wav_pcm16(str(up), CO.float_to_pcm16(y), 16000)
+    label, prob = dp.predict_file(str(up))
+    y_in, _ = rsd_amd.load_audio(str(up))
+    want_pcm = CO.clean_audio(y_in, 16000, 0.8)
+    got_pcm, _ = O.read_wav_pcm16(str(clear / "fresh upload.wav"))
+    assert (got_pcm != want_pcm).sum() <= 1
+    feats = O.extract_features(O.pcm16_to_float(got_pcm), 16000)
+    x = torch.from_numpy(feats.reshape(1, -1)).cuda()
+    assert label == classes[int(rf.predict(x)[0])] and label in classes
+    assert max(abs(prob[k] - float(rf.predict_proba(x)[0][i])) for i, k in enumerate(classes)) <= 0.0051
+    assert dp.predict_file(str(up))[0] == label                              # memoised cleaned file
+    # (iii) silence: the gate is non-finite, main1 falls back to the input path; features of silence still classify
+    sil = tmp_path / "silence.wav"
+    rsd_amd.write_wav_pcm16(str(sil), np.zeros(8000, np.int16), 16000)
+    label_s, prob_s = dp.predict_file(str(sil))
+    assert label_s in classes and not (clear / "silence.wav").exists()
+    # (iv) unreadable
+    assert dp.predict_file(str(tmp_path / "nope.wav")) == (None, None)
+    rf.close()
