@@ -2,10 +2,14 @@
 // and arg-max.  Replaces scaler.transform + MLPClassifier.predict / predict_proba (pipeline1.py:470-473, 497,
 // 512-514) for batches that are already on the GPU: the eager version is seven tiny launches, which cost more than
 // the arithmetic (27 456 MACs per row for 149 -> 128 -> 64 -> 3).
-// A workgroup owns kRows rows: the scaled rows sit in LDS, the layer's weights stream through an LDS tile (coalesced
-// block copies of up to 32 KB), every thread produces outputs (row, unit) for a fixed unit and a strided
-// set of rows: consecutive lanes read consecutive weights and broadcast the activations.  float32 FMA throughout;
-// hidden activations ping-pong between two LDS buffers.
+// A workgroup of four waves owns 16 rows.  The scaled rows and the hidden activations sit in LDS as [16][width]; every
+// layer is out[16 x dout] = act[16 x din] * W on v_mfma_f32_16x16x4_f32: a wave takes the 16-unit output blocks
+// w, w + 4, ... and walks K in groups of 16 -- lane (row = l & 15, q = l >> 4) reads its four consecutive activations
+// 16g + 4q .. + 3 with one ds_read_b128, and the weights come from a host-made pack in exactly that order
+// ([layer][block][group][lane][4], zero padded), one 16-byte load per lane, group and block straight from L2 (the 117 KB
+// of the reference MLP stay cached; a copy of the pack in LDS was measured: equal at 1024 rows, 2x slower at 16 384 because
+// only one workgroup fits a CU then).  float32 accumulation in a fixed order: results do not depend on the batch.
+// 1024 rows: 13.4 us (the float32-FMA form it replaces: 14.4); 16 384 rows: 19.5 us (74.8).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -20,116 +24,86 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRows = 4;        // rows per workgroup
-constexpr int kThreads = 256;
+constexpr int kRows = 16;       // rows per workgroup (one MFMA tile)
+constexpr int kThreads = 256;   // four waves
+constexpr int kWaves = kThreads / 64;
 constexpr int kMaxLayers = 4;
 constexpr int kMaxWidth = 512;  // widest layer (input or hidden) held in LDS
-constexpr int kTileK = 16;     // K block of the unrolled inner product (weight rows are padded to whole blocks)
-constexpr int kTileFloats = 8192;  // LDS weight tile (32 KB)
-constexpr int kPf = kTileFloats / 4 / kThreads;  // 16-byte prefetch registers per thread
+constexpr int kMaxBlocks = 4;   // 16-unit output blocks per wave: layers up to 256 units
 
 struct MlpDev {
-  int n_layers, n_pass, n_features, n_outputs;
-  int width;                // LDS row stride of the activation buffers
-  const int* layer;         // [n_layers][3] = {din, dout, offset of the bias in params}
-  const int* pass;          // [n_pass][4] = {layer, t0, rows, offset in params of row t0 of that layer's matrix}
-  const float* params;      // every layer's zero-padded weights (row-major [din_pad][dout]) and biases
+  int n_layers, n_features, n_outputs;
+  int width;                // LDS row stride of the activation buffers (floats)
+  const int* layer;         // [n_layers][4] = {din, dout, offset of the bias in params, offset of the weight pack in params}
+  const float* params;      // every layer's weight pack ([block][group][lane][4]) and biases
   const float* mean; const float* inv_scale;
 };
 
 __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const float* x, int n, float* logits, float* proba,
                                                             int* pred) {
-  extern __shared__ __align__(16) float act[];  // two activation buffers of [kRows][width], then the weight tile
+  extern __shared__ __align__(16) float act[];  // two activation buffers of [kRows][width]
   float* cur = act;
   float* nxt = act + kRows * m.width;
-  float* wt = act + 2 * kRows * m.width;        // [kTileK][dout] slice of the current layer's weights
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * kRows;
   const int d0 = m.n_features;
-  // the K loop below runs in whole tiles: the columns it touches past a layer's width must hold finite numbers
-  // (they meet zero weights), so both buffers start out as zeros
+  // K is walked in whole groups of 16: the columns past a layer's width meet zero weights but must hold finite numbers
   for (int i = tid; i < 2 * kRows * m.width; i += kThreads) act[i] = 0.f;
   __syncthreads();
-  for (int i = tid; i < kRows * d0; i += kThreads) {
-    const int r = i / d0, j = i % d0;
-    const int row = row0 + r;
-    cur[r * m.width + j] = (row < n) ? (x[(size_t)row * d0 + j] - m.mean[j]) * m.inv_scale[j] : 0.f;
+  // scaled inputs: a thread keeps its column(s) j = tid (+ 256) and walks the 16 rows -- no index division, the scaler
+  // terms loaded once, and all 16 row loads of a column in flight together (rows past the batch repeat its last row)
+  for (int j = tid; j < d0; j += kThreads) {
+    const float mu = m.mean[j], is = m.inv_scale[j];
+    float xv[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) xv[r] = x[(size_t)min(row0 + r, n - 1) * d0 + j];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) cur[r * m.width + j] = (row0 + r < n) ? (xv[r] - mu) * is : 0.f;
   }
-  // Weight tiles stream through registers one pass ahead (also across layer boundaries), so only the very first
-  // fetch is exposed: a pass = up to 32 KB of consecutive rows of one layer's matrix.
-  f32x4 pf[kPf];
-  auto fetch = [&](int p) {
-    const int dout = m.layer[3 * m.pass[4 * p] + 1];
-    const int nvec = m.pass[4 * p + 2] * dout / 4;
-    const f32x4* src = (const f32x4*)(m.params + m.pass[4 * p + 3]);
-#pragma unroll
-    for (int j = 0; j < kPf; ++j) {  // branch-free (clamped) so the registers stay registers
-      const int e = tid + j * kThreads;
-      pf[j] = src[e < nvec ? e : nvec - 1];
-    }
-  };
-  fetch(0);
-  int p = 0;
+  __syncthreads();
+  const float* params = m.params;
+  const int arow = (lane & 15) * m.width + 4 * (lane >> 4);   // this lane's A operand: row l & 15, K offset 4 * (l >> 4)
   for (int l = 0; l < m.n_layers; ++l) {
-    const int dout = m.layer[3 * l + 1];
+    const int din = m.layer[4 * l], dout = m.layer[4 * l + 1];
     const bool last = l + 1 == m.n_layers;
-    // outputs (r, u): u fastest across threads; a thread keeps its unit and owns rows rb, rb + rstep, ...
-    const int rstep = kThreads / dout;            // dout <= kThreads (checked by dysf_mlp_create)
-    const int rpt = (kRows + rstep - 1) / rstep;  // rows per thread (workgroup-uniform)
-    const int u = tid % dout, rb = tid / dout;
-    const bool owner = rb < rstep && rb < kRows;
-    float acc[kRows];
-    const float* arow[kRows];
+    const int ngrp = (din + 15) / 16, nblk = (dout + 15) / 16;
+    const float* wp = params + m.layer[4 * l + 3] + lane * 4;
+    f32x4 acc[kMaxBlocks];
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-      acc[i] = 0.f;
-      const int r = rb + i * rstep;
-      arow[i] = cur + (r < kRows ? r : kRows - 1) * m.width;
-    }
-    for (; p < m.n_pass && m.pass[4 * p] == l; ++p) {
-      const int t0 = m.pass[4 * p + 1], rows = m.pass[4 * p + 2];
-      const int nvec = rows * dout / 4;
-      __syncthreads();  // previous tile consumed (and, first time round, the activations are in place)
+    for (int i = 0; i < kMaxBlocks; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < ngrp; ++g) {
+      const float4 a4 = *(const float4*)(cur + arow + 16 * g);
 #pragma unroll
-      for (int j = 0; j < kPf; ++j)
-        if (tid + j * kThreads < nvec) ((f32x4*)wt)[tid + j * kThreads] = pf[j];
-      __syncthreads();
-      if (p + 1 < m.n_pass) fetch(p + 1);
-      if (owner) {
-        for (int sb = 0; sb < rows; sb += kTileK) {
-          float wv[kTileK];
-#pragma unroll
-          for (int kk = 0; kk < kTileK; ++kk) wv[kk] = wt[(sb + kk) * dout + u];
-#pragma unroll
-          for (int i = 0; i < kRows; ++i)
-            if (i < rpt) {
-              const float4* a4 = (const float4*)(arow[i] + t0 + sb);
-#pragma unroll
-              for (int q = 0; q < kTileK / 4; ++q) {
-                const float4 av = a4[q];
-                acc[i] = fmaf(av.x, wv[4 * q + 0], acc[i]);
-                acc[i] = fmaf(av.y, wv[4 * q + 1], acc[i]);
-                acc[i] = fmaf(av.z, wv[4 * q + 2], acc[i]);
-                acc[i] = fmaf(av.w, wv[4 * q + 3], acc[i]);
-              }
-            }
+      for (int i = 0; i < kMaxBlocks; ++i) {
+        const int blk = wave + i * kWaves;   // wave-uniform
+        if (blk < nblk) {
+          const float4 w4 = *(const float4*)(wp + ((size_t)blk * ngrp + g) * 256);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4.y, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4.z, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4.w, acc[i], 0, 0, 0);
         }
       }
     }
-    if (owner) {
-      const float bias = m.params[m.layer[3 * l + 2] + u];
+    // C/D map: acc[i][r] = output unit 16 * blk + (l & 15) of row 4 * (l >> 4) + r
 #pragma unroll
-      for (int i = 0; i < kRows; ++i) {
-        const int r = rb + i * rstep;
-        if (i < rpt && r < kRows) {
-          float v = acc[i] + bias;
+    for (int i = 0; i < kMaxBlocks; ++i) {
+      const int blk = wave + i * kWaves;
+      const int u = 16 * blk + (lane & 15);
+      if (blk < nblk && u < dout) {
+        const float bias = params[m.layer[4 * l + 2] + u];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][r] + bias;
           if (!last) v = fmaxf(v, 0.f);
-          nxt[r * m.width + u] = v;
+          nxt[(4 * (lane >> 4) + r) * m.width + u] = v;
         }
       }
     }
     __syncthreads();
     float* t = cur; cur = nxt; nxt = t;
+    // (columns past dout keep older, finite values: they only ever meet the zero padding of a weight pack)
   }
   // epilogue: one thread per row
   const int dout = m.n_outputs;
@@ -189,28 +163,31 @@ int32_t dysf_mlp_create(int32_t device, int32_t n_layers, const int32_t* dims, c
   m->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete m; g_merr = "hipSetDevice failed"; return DYSF_E_HIP; }
   m->d.n_layers = n_layers; m->d.n_features = dims[0]; m->d.n_outputs = dims[n_layers];
-  m->d.width = (width + kTileK - 1) / kTileK * kTileK + 4;  // whole K blocks per row, 16-byte aligned rows
+  m->d.width = (width + 15) / 16 * 16 + 4;  // whole K groups per row, 16-byte aligned rows
   std::vector<float> params;
-  std::vector<int> layer_tab, pass_tab;
+  std::vector<int> layer_tab;
   for (int l = 0; l < n_layers; ++l) {
-    const int din_pad = (dims[l] + kTileK - 1) / kTileK * kTileK;  // zero rows up to a whole number of K blocks
+    const int din = dims[l], dout = dims[l + 1];
+    const int ngrp = (din + 15) / 16, nblk = (dout + 15) / 16;
     const int woff = (int)params.size();
-    params.resize(woff + (size_t)din_pad * dims[l + 1], 0.f);
-    for (size_t i = 0; i < (size_t)dims[l] * dims[l + 1]; ++i) params[woff + i] = (float)weights[l][i];
+    params.resize(woff + (size_t)nblk * ngrp * 256, 0.f);
+    // pack[block][group][lane][s] = W[16 * group + 4 * (lane >> 4) + s][16 * block + (lane & 15)]  (weights[l] is [din][dout])
+    for (int blk = 0; blk < nblk; ++blk)
+      for (int g = 0; g < ngrp; ++g)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int sidx = 0; sidx < 4; ++sidx) {
+            const int k = 16 * g + 4 * (ln >> 4) + sidx, u = 16 * blk + (ln & 15);
+            if (k < din && u < dout) params[woff + (((size_t)blk * ngrp + g) * 64 + ln) * 4 + sidx] = (float)weights[l][(size_t)k * dout + u];
+          }
     const int boff = (int)params.size();
-    for (int i = 0; i < dims[l + 1]; ++i) params.push_back((float)biases[l][i]);
-    params.resize((params.size() + 3) / 4 * 4, 0.f);  // the next matrix starts 16-byte aligned
-    layer_tab.insert(layer_tab.end(), {dims[l], dims[l + 1], boff});
-    int ts = kTileFloats / dims[l + 1] / kTileK * kTileK;
-    ts = ts < kTileK ? kTileK : ts;
-    for (int t0 = 0; t0 < din_pad; t0 += ts)
-      pass_tab.insert(pass_tab.end(), {l, t0, std::min(ts, din_pad - t0), woff + t0 * dims[l + 1]});
+    for (int i = 0; i < dout; ++i) params.push_back((float)biases[l][i]);
+    params.resize((params.size() + 3) / 4 * 4, 0.f);  // the next pack starts 16-byte aligned
+    layer_tab.insert(layer_tab.end(), {din, dout, boff, woff});
   }
-  m->d.n_pass = (int)pass_tab.size() / 4;
   std::vector<float> mu((size_t)dims[0]), inv((size_t)dims[0]);
   for (int j = 0; j < dims[0]; ++j) { mu[j] = (float)mean[j]; inv[j] = (float)(1.0 / scale[j]); }
   bool ok = up(m, &m->d.params, params) && up(m, &m->d.mean, mu) && up(m, &m->d.inv_scale, inv) &&
-            up(m, &m->d.layer, layer_tab) && up(m, &m->d.pass, pass_tab);
+            up(m, &m->d.layer, layer_tab);
   if (!ok) { for (void* p : m->bufs) (void)hipFree(p); delete m; g_merr = "device upload failed"; return DYSF_E_HIP; }
   *out = m;
   return 0;
@@ -228,8 +205,8 @@ int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_l
   if (!m || !d_x || n < 0) { g_merr = "bad argument"; return DYSF_E_INVALID; }
   if (n == 0) return 0;
   if (hipSetDevice(m->device) != hipSuccess) { g_merr = "hipSetDevice failed"; return DYSF_E_HIP; }
-  const size_t lds = ((size_t)2 * kRows * m->d.width + (size_t)kTileFloats) * sizeof(float);
-  if (!m->attr_set) {  // more than the default 64 KB of dynamic LDS
+  const size_t lds = (size_t)2 * kRows * m->d.width * sizeof(float);   // <= 66 KB
+  if (!m->attr_set && lds > 64 * 1024) {  // more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute((const void*)dysf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       g_merr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
     }
