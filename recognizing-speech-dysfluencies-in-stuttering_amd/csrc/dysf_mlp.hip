@@ -6,10 +6,12 @@
 // layer is out[16 x dout] = act[16 x din] * W on v_mfma_f32_16x16x4_f32: a wave takes the 16-unit output blocks
 // w, w + 4, ... and walks K in groups of 16 -- lane (row = l & 15, q = l >> 4) reads its four consecutive activations
 // 16g + 4q .. + 3 with one ds_read_b128, and the weights come from a host-made pack in exactly that order
-// ([layer][block][group][lane][4], zero padded), one 16-byte load per lane, group and block straight from L2 (the 117 KB
-// of the reference MLP stay cached; a copy of the pack in LDS was measured: equal at 1024 rows, 2x slower at 16 384 because
-// only one workgroup fits a CU then).  float32 accumulation in a fixed order: results do not depend on the batch.
-// 1024 rows: 13.4 us (the float32-FMA form it replaces: 14.4); 16 384 rows: 19.5 us (74.8).
+// ([layer][block][group][lane][4], zero padded): one 16-byte load per lane, group and block straight from L2 / HBM, eight
+// groups requested before the first is used (in the pipeline the feature kernels have just streamed through L2, so these
+// loads are not cheap: per-group loads inside the K loop cost 25 us per launch, a chunked prefetch sized for four blocks
+// per wave cost co-resident kernels their registers, hence the template on the blocks a wave really owns).  A copy of the
+// pack in LDS was measured too: equal at 1024 rows, twice as slow at 16 384 (one workgroup per CU).
+// float32 accumulation in a fixed order: results do not depend on the batch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,6 +41,8 @@ struct MlpDev {
   const float* mean; const float* inv_scale;
 };
 
+// NB: 16-unit output blocks a wave may own (the widest layer decides: 1, 2 or 4) -- sizes the weight registers
+template <int NB>
 __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const float* x, int n, float* logits, float* proba,
                                                             int* pred) {
   extern __shared__ __align__(16) float act[];  // two activation buffers of [kRows][width]
@@ -69,26 +73,40 @@ __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const floa
     const bool last = l + 1 == m.n_layers;
     const int ngrp = (din + 15) / 16, nblk = (dout + 15) / 16;
     const float* wp = params + m.layer[4 * l + 3] + lane * 4;
-    f32x4 acc[kMaxBlocks];
+    f32x4 acc[NB];
 #pragma unroll
-    for (int i = 0; i < kMaxBlocks; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < ngrp; ++g) {
-      const float4 a4 = *(const float4*)(cur + arow + 16 * g);
+    for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // eight K groups at a time: all weight loads of the chunk first (they come from L2 or, after the feature kernels have
+    // streamed through it, from HBM -- one exposed latency per chunk instead of one per group), then the MFMAs
+    constexpr int GC = 8;
+    for (int g0 = 0; g0 < ngrp; g0 += GC) {
+      float4 w4[GC][NB];
 #pragma unroll
-      for (int i = 0; i < kMaxBlocks; ++i) {
-        const int blk = wave + i * kWaves;   // wave-uniform
-        if (blk < nblk) {
-          const float4 w4 = *(const float4*)(wp + ((size_t)blk * ngrp + g) * 256);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4.y, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4.z, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4.w, acc[i], 0, 0, 0);
+      for (int gi = 0; gi < GC; ++gi)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int blk = wave + i * kWaves;   // wave-uniform
+          if (g0 + gi < ngrp && blk < nblk) w4[gi][i] = *(const float4*)(wp + ((size_t)blk * ngrp + g0 + gi) * 256);
+        }
+#pragma unroll
+      for (int gi = 0; gi < GC; ++gi) {
+        if (g0 + gi >= ngrp) break;
+        const float4 a4 = *(const float4*)(cur + arow + 16 * (g0 + gi));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int blk = wave + i * kWaves;
+          if (blk < nblk) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4[gi][i].x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4[gi][i].y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4[gi][i].z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4[gi][i].w, acc[i], 0, 0, 0);
+          }
         }
       }
     }
     // C/D map: acc[i][r] = output unit 16 * blk + (l & 15) of row 4 * (l >> 4) + r
 #pragma unroll
-    for (int i = 0; i < kMaxBlocks; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int blk = wave + i * kWaves;
       const int u = 16 * blk + (lane & 15);
       if (blk < nblk && u < dout) {
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const floa
 
 struct DysfMlp {
   int device = 0;
+  int blocks_per_wave = 1;   // of the widest layer: ceil(ceil(dout / 16) / 4)
   bool attr_set = false;
   MlpDev d{};
   std::vector<void*> bufs;
@@ -183,6 +202,7 @@ int32_t dysf_mlp_create(int32_t device, int32_t n_layers, const int32_t* dims, c
     for (int i = 0; i < dout; ++i) params.push_back((float)biases[l][i]);
     params.resize((params.size() + 3) / 4 * 4, 0.f);  // the next pack starts 16-byte aligned
     layer_tab.insert(layer_tab.end(), {din, dout, boff, woff});
+    m->blocks_per_wave = std::max(m->blocks_per_wave, (nblk + kWaves - 1) / kWaves);
   }
   std::vector<float> mu((size_t)dims[0]), inv((size_t)dims[0]);
   for (int j = 0; j < dims[0]; ++j) { mu[j] = (float)mean[j]; inv[j] = (float)(1.0 / scale[j]); }
@@ -206,14 +226,18 @@ int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_l
   if (n == 0) return 0;
   if (hipSetDevice(m->device) != hipSuccess) { g_merr = "hipSetDevice failed"; return DYSF_E_HIP; }
   const size_t lds = (size_t)2 * kRows * m->d.width * sizeof(float);   // <= 66 KB
-  if (!m->attr_set && lds > 64 * 1024) {  // more than the default 64 KB of dynamic LDS
-    if (hipFuncSetAttribute((const void*)dysf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      g_merr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
+  auto launch = [&](auto kernel) -> bool {
+    if (!m->attr_set && lds > 64 * 1024) {  // more than the default 64 KB of dynamic LDS
+      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+      m->attr_set = true;
     }
-    m->attr_set = true;
-  }
-  hipLaunchKernelGGL(dysf_mlp_kernel, dim3((n + kRows - 1) / kRows), dim3(kThreads), lds, (hipStream_t)stream, m->d, d_x,
-                     n, d_logits, d_proba, d_pred);
+    hipLaunchKernelGGL(kernel, dim3((n + kRows - 1) / kRows), dim3(kThreads), lds, (hipStream_t)stream, m->d, d_x, n, d_logits,
+                       d_proba, d_pred);
+    return true;
+  };
+  const bool ok = m->blocks_per_wave <= 1 ? launch(dysf_mlp_kernel<1>) : m->blocks_per_wave == 2 ? launch(dysf_mlp_kernel<2>)
+                                                                                                  : launch(dysf_mlp_kernel<4>);
+  if (!ok) { g_merr = "hipFuncSetAttribute failed"; return DYSF_E_HIP; }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_merr = hipGetErrorString(e); return DYSF_E_HIP; }
   return 0;
