@@ -56,7 +56,7 @@ CSRC = os.path.join(ROOT, "recognizing-speech-dysfluencies-in-stuttering_amd", "
 def kernel_source_id():
     """Short hash of the kernel sources: ties counter files under profiles/ to the build they were measured on."""
     h = hashlib.sha256()
-    for name in ("dysf_kernels.hip", "dysf_fft.hpp", "dysf_kernels.h", "dysf_cnn.hip"):
+    for name in ("dysf_kernels.hip", "dysf_fft.hpp", "dysf_kernels.h", "dysf_cnn.hip", "dysf_mlp.hip"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:12]
