@@ -1078,3 +1078,31 @@ def test_deployed_predictor_object_with_cleaning(golden_dir, tmp_path):
     # (iv) unreadable
     assert dp.predict_file(str(tmp_path / "nope.wav")) == (None, None)
     rf.close()
+
+
+@pytest.mark.parametrize("dims", [(37, 5), (149, 200, 17, 3), (512, 256, 256, 130, 7), (20, 16, 16), (300, 100, 2)],
+                         ids=["1layer", "wide_hidden_nb4", "max_sizes", "exact_16s", "two_layer"])
+def test_fused_mlp_head_generic_shapes(dims):
+    """dysf_mlp_kernel for layer shapes other than the reference's 149-128-64-3: inputs and widths that are not multiples
+    of 16, up to the 512-input / 256-unit limits, one to four layers (all three blocks-per-wave builds), ragged batch
+    tails -- against the eager float64 module (the MFMA accumulates float32: 2e-5 of the logit scale)."""
+    from rsd_amd.classifier import FusedMLPHead, MLPHead
+    rng = np.random.default_rng(len(dims) * 1000 + dims[0])
+    ws = [rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]) for i in range(len(dims) - 1)]
+    bs = [rng.standard_normal(dims[i + 1]) * 0.1 for i in range(len(dims) - 1)]
+    mean, scale = rng.standard_normal(dims[0]), rng.uniform(0.5, 2.0, dims[0])
+    fused = FusedMLPHead(mean, scale, ws, bs)
+    eager = MLPHead(mean, scale, ws, bs, dtype=torch.float64).cuda()
+    for n in (1, 15, 16, 17, 1000):
+        x = torch.from_numpy(rng.standard_normal((n, dims[0])).astype(np.float32)).cuda()
+        got, want = fused(x).cpu().numpy(), eager(x).cpu().numpy()
+        assert got.shape == want.shape == (n, dims[-1])
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (n, np.abs(got - want).max())
+        assert torch.equal(fused(x), fused(x))                              # fixed summation order
+        p = fused.predict_proba(x).cpu().numpy()
+        assert np.abs(p.sum(axis=1) - 1).max() <= 1e-5
+        clear = np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2] > 1e-3 if dims[-1] > 1 else np.ones(n, bool)
+        assert (fused.predict(x).cpu().numpy()[clear] == want.argmax(axis=1)[clear]).all()
+    fused.close()
+    with pytest.raises(rsd_amd.DysfError):
+        FusedMLPHead(np.zeros(8), np.ones(8), [rng.standard_normal((8, 300))], [np.zeros(300)])   # wider than 256 units
