@@ -1194,77 +1194,83 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   // one thread per peak -- to (interpolated magnitude, histogram bin) and appended to the clip's list in the workspace.
   int npk = 0;
   {
-    // Two frames per wave and round; a lane owns four consecutive bins of every 256-bin slice of its frame's row (one
-    // 16-byte load per slice, all slices of both frames requested before the first is looked at), the neighbours of
-    // its first and last bin come from the adjacent lanes.
+    // A wave walks its frames t = wave, wave + NW, ... on its own: no workgroup barrier inside the pass.  A lane owns four
+    // consecutive bins of every 256-bin slice of the frame's row (one 16-byte load per slice; the next frame's row is
+    // requested before this one is looked at), the neighbours of its first and last bin come from the adjacent lanes.
+    // Local maxima are parked in the wave's private slice of the LDS list (positions from ballot pop-counts, no atomics);
+    // when the slice cannot take another frame, and at the end, the wave converts its maxima -- one lane per peak -- to
+    // (interpolated magnitude, histogram bin) and appends them to the clip's list in the workspace (order is immaterial).
     constexpr int NV = NVT;                        // 256-bin slices held per frame (the launcher checks that they reach pip_kmax)
-    constexpr int FPR = 2;                         // frames per wave per round
     const float* rowmax = a.ws_rowmax + (size_t)clip * a.t_max;
     const int nv = min(NV, (a.pip_kmax + 1 + 255) / 256);   // slices that reach the pitch band (wave-uniform)
-    const int per_round = NW * FPR * ((a.pip_kmax - a.pip_kmin) / 2 + 2);   // most local maxima one round can park
+    const int per_frame = (a.pip_kmax - a.pip_kmin) / 2 + 2;   // most local maxima one frame can park
+    const int rcap = a.cand_cap / NW;                          // the wave's slice (>= 2 * per_frame: dysf_capi.hip)
+    float4* mine = sm_cand + wave * rcap;
     if (tid == 0) sm_cnt = 0;
     __syncthreads();
-    for (int t0 = 0; t0 < T; t0 += NW * FPR) {
-      float4 v[FPR][NV];
-      float ref[FPR];
-#pragma unroll
-      for (int f = 0; f < FPR; ++f) {
-        const int t = t0 + wave + f * NW;
-        const float* row = S + (size_t)(t < T ? t : T - 1) * a.s_stride + 4 * lane;
-        ref[f] = mul_rn(0.1f, rowmax[t < T ? t : T - 1]);
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (i < nv) v[f][i] = (256 * i + 4 * lane + 3 < a.s_stride) ? *(const float4*)(row + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int wcnt = 0;   // maxima parked in the slice (wave-uniform)
+    auto flush = [&]() {
+      wave_lds_sync();
+      int gbase = 0;
+      if (lane == 0) gbase = atomicAdd(&sm_cnt, wcnt);
+      gbase = __builtin_amdgcn_readfirstlane(gbase);
+      for (int i = lane; i < wcnt; i += 64) {
+        const float4 c = mine[i];
+        float mag; int bin;
+        peak_to_mag_bin<NC>(__float_as_int(c.x), c.y, c.z, c.w, a, &mag, &bin);
+        if (gbase + i < (int)a.ws_peak_stride) { pk_mag[gbase + i] = mag; pk_bin[gbase + i] = bin; }
       }
+      wave_lds_sync();
+      wcnt = 0;
+    };
+    float4 vn[NV];
+    float refn = 0.f;
+    auto request = [&](int t) {
+      const float* row = S + (size_t)(t < T ? t : T - 1) * a.s_stride + 4 * lane;
+      refn = rowmax[t < T ? t : T - 1];
 #pragma unroll
-      for (int f = 0; f < FPR; ++f) {
-        const int t = t0 + wave + f * NW;
-        if (t >= T) continue;   // wave-uniform
+      for (int i = 0; i < NV; ++i)
+        if (i < nv) vn[i] = (256 * i + 4 * lane + 3 < a.s_stride) ? *(const float4*)(row + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    request(wave);
+    for (int t = wave; t < T; t += NW) {
+      float4 v[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          if (i >= nv) continue;
-          const float4 c = v[f][i];
-          // left neighbour of .x: lane - 1's .w (lane 0: the previous slice's lane 63); right neighbour of .w: lane + 1's .x
-          float left = __shfl_up(c.w, 1), right = __shfl_down(c.x, 1);
-          if (lane == 0) left = 0.f;
-          if (i > 0) { const float pw = __shfl(v[f][i - 1].w, 63); if (lane == 0) left = pw; }
-          float nx = 0.f;
-          if (i + 1 < NV && i + 1 < nv) nx = __shfl(v[f][i + 1].x, 0);
-          else if (lane == 63) nx = 0.f;
-          if (lane == 63) right = nx;
-          const float xs[6] = {left, c.x, c.y, c.z, c.w, right};
+      for (int i = 0; i < NV; ++i) v[i] = vn[i];
+      const float ref = mul_rn(0.1f, refn);
+      if (t + NW < T) request(t + NW);
+      if (wcnt + per_frame > rcap) flush();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int k = 256 * i + 4 * lane + j;
-            const float x0 = xs[j + 1], xm = xs[j], x1 = xs[j + 2];
-            const float z0 = x0 > ref[f] ? x0 : 0.f, zm = xm > ref[f] ? xm : 0.f, z1 = x1 > ref[f] ? x1 : 0.f;
-            const bool is_peak = (k >= a.pip_kmin) && (k < a.pip_kmax) && (z0 > zm) && (z0 >= z1);
-            const unsigned long long mask = __ballot(is_peak);
-            if (mask != 0ull) {
-              int base = 0;
-              if (lane == 0) base = atomicAdd(&sm_cnt, __popcll(mask));
-              base = __shfl(base, 0);
-              if (is_peak) sm_cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(__int_as_float(k), x0, xm, x1);
-            }
+      for (int i = 0; i < NV; ++i) {
+        if (i >= nv) continue;
+        const float4 c = v[i];
+        // left neighbour of .x: lane - 1's .w (lane 0: the previous slice's lane 63); right neighbour of .w: lane + 1's .x
+        float left = __shfl_up(c.w, 1), right = __shfl_down(c.x, 1);
+        if (lane == 0) left = 0.f;
+        if (i > 0) { const float pw = __shfl(v[i - 1].w, 63); if (lane == 0) left = pw; }
+        float nx = 0.f;
+        if (i + 1 < NV && i + 1 < nv) nx = __shfl(v[i + 1].x, 0);
+        else if (lane == 63) nx = 0.f;
+        if (lane == 63) right = nx;
+        const float xs[6] = {left, c.x, c.y, c.z, c.w, right};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 256 * i + 4 * lane + j;
+          const float x0 = xs[j + 1], xm = xs[j], x1 = xs[j + 2];
+          const float z0 = x0 > ref ? x0 : 0.f, zm = xm > ref ? xm : 0.f, z1 = x1 > ref ? x1 : 0.f;
+          const bool is_peak = (k >= a.pip_kmin) && (k < a.pip_kmax) && (z0 > zm) && (z0 >= z1);
+          const unsigned long long mask = __ballot(is_peak);
+          if (mask != 0ull) {
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (is_peak) mine[wcnt + below] = make_float4(__int_as_float(k), x0, xm, x1);
+            wcnt += __popcll(mask);
           }
         }
       }
-      __syncthreads();
-      const int cnt = sm_cnt;
-      // convert and flush only when the next round might not fit (typical clips: once, at the end)
-      if (cnt + per_round > a.cand_cap || t0 + NW * FPR >= T) {
-        for (int i = tid; i < cnt; i += NT) {
-          const float4 c = sm_cand[i];
-          float mag; int bin;
-          peak_to_mag_bin<NC>(__float_as_int(c.x), c.y, c.z, c.w, a, &mag, &bin);
-          if (npk + i < (int)a.ws_peak_stride) { pk_mag[npk + i] = mag; pk_bin[npk + i] = bin; }
-        }
-        npk += cnt;
-        __syncthreads();
-        if (tid == 0) sm_cnt = 0;
-        __syncthreads();
-      }
     }
+    flush();
+    __syncthreads();
+    npk = sm_cnt;
     if (tid == 0) a.ws_peak_cnt[clip] = npk;   // (dysf_debug_peaks)
   }
   npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
