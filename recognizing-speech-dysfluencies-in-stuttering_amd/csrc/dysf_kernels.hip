@@ -1245,13 +1245,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
         if (i >= nv) continue;
         const float4 c = v[i];
         // left neighbour of .x: lane - 1's .w (lane 0: the previous slice's lane 63); right neighbour of .w: lane + 1's .x
-        float left = __shfl_up(c.w, 1), right = __shfl_down(c.x, 1);
-        if (lane == 0) left = 0.f;
-        if (i > 0) { const float pw = __shfl(v[i - 1].w, 63); if (lane == 0) left = pw; }
-        float nx = 0.f;
-        if (i + 1 < NV && i + 1 < nv) nx = __shfl(v[i + 1].x, 0);
-        else if (lane == 63) nx = 0.f;
-        if (lane == 63) right = nx;
+        // (whole-wave DPP shifts, zero shifted in at the ends; the slice seams through v_readlane)
+        float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.w), 0x138, 0xf, 0xf, false));    // wave_shr:1
+        float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.x), 0x130, 0xf, 0xf, false));   // wave_shl:1
+        if (i > 0) { const float pw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i - 1].w), 63)); if (lane == 0) left = pw; }
+        if (i + 1 < NV && i + 1 < nv) { const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i + 1].x), 0)); if (lane == 63) right = nx; }
         const float xs[6] = {left, c.x, c.y, c.z, c.w, right};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
