@@ -499,13 +499,19 @@ __device__ __forceinline__ void peak_to_mag_bin(int k, float x0, float xm, float
 // r-th smallest (0-based) of the n positive floats in v (bit order = numeric order), by most-significant-byte-first
 // radix selection: four passes over v, each with a 256-bin LDS histogram of the values that still match the prefix.
 // All threads call; hist = 256 ints of LDS scratch, ctl = 2 ints.
-template <int NT>
-__device__ float block_select(const float* v, int n, int r, int* hist, int* ctl) {
+// reg[j] caches v[threadIdx.x + j * NT] for j < KR (the four passes then read registers, not memory).
+template <int NT, int KR>
+__device__ float block_select(const float* v, const float (&reg)[KR], int n, int r, int* hist, int* ctl) {
   unsigned prefix = 0u, mask = 0u;
   for (int pass = 3; pass >= 0; --pass) {
     for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      const unsigned u = __float_as_uint(reg[j]);
+      if ((int)threadIdx.x + j * NT < n && (u & mask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1);
+    }
+    for (int i = threadIdx.x + KR * NT; i < n; i += NT) {
       const unsigned u = __float_as_uint(v[i]);
       if ((u & mask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1);
     }
@@ -519,6 +525,41 @@ __device__ float block_select(const float* v, int n, int r, int* hist, int* ctl)
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (l >= o) inc += t; }
       const int before = inc - tot;
       if (r >= before && r < inc) {  // exactly one lane: the r-th value falls into one of its four bins
+        int d = 4 * l, c = before;
+        if (r >= c + h0) { c += h0; ++d; if (r >= c + h1) { c += h1; ++d; if (r >= c + h2) { c += h2; ++d; } } }
+        ctl[0] = d; ctl[1] = r - c;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)ctl[0] << (8 * pass);
+    mask |= 0xffu << (8 * pass);
+    r = ctl[1];
+    __syncthreads();
+  }
+  return __uint_as_float(prefix);
+}
+
+// The same selection with nothing cached (metrics kernel).
+template <int NT>
+__device__ float block_select(const float* v, int n, int r, int* hist, int* ctl) {
+  unsigned prefix = 0u, mask = 0u;
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) {
+      const unsigned u = __float_as_uint(v[i]);
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (l >= o) inc += t; }
+      const int before = inc - tot;
+      if (r >= before && r < inc) {
         int d = 4 * l, c = before;
         if (r >= c + h0) { c += h0; ++d; if (r >= c + h1) { c += h1; ++d; if (r >= c + h2) { c += h2; ++d; } } }
         ctl[0] = d; ctl[1] = r - c;
@@ -1274,18 +1315,32 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
   int tune = 50;
   if (npk > 0) {
+    // this thread's share of the peak list in registers (all loads in flight together): the median's four radix passes,
+    // the upper-median pass and the histogram pass read it from there; lists beyond KR * NT peaks fall back to memory
+    constexpr int KR = 8;
+    float rmag[KR];
+    int rbin[KR];
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      const int idx = min(tid + j * NT, npk - 1);
+      rmag[j] = pk_mag[idx];
+      rbin[j] = pk_bin[idx];
+    }
     float thr;
     if (npk & 1) {
-      thr = block_select<NT>(pk_mag, npk, npk / 2, sm_i + 128, sm_i);
+      thr = block_select<NT, KR>(pk_mag, rmag, npk, npk / 2, sm_i + 128, sm_i);
     } else {
       // np.median of an even count: mean of the two middle order statistics.  The upper one follows from the lower one in a
       // single pass: it is the lower value again if that value fills index npk / 2 too, else the smallest larger element.
-      const float lo = block_select<NT>(pk_mag, npk, npk / 2 - 1, sm_i + 128, sm_i);
+      const float lo = block_select<NT, KR>(pk_mag, rmag, npk, npk / 2 - 1, sm_i + 128, sm_i);
       if (tid == 0) { sm_i[2] = 0; sm_i[3] = 0x7f800000; }
       __syncthreads();
       int c_le = 0;
       unsigned mn = 0x7f800000u;   // +inf; the magnitudes that matter are positive floats: their bits order like the values
-      for (int i = tid; i < npk; i += NT) {
+#pragma unroll
+      for (int j = 0; j < KR; ++j)
+        if (tid + j * NT < npk) { if (rmag[j] <= lo) ++c_le; else mn = min(mn, __float_as_uint(rmag[j])); }
+      for (int i = tid + KR * NT; i < npk; i += NT) {
         const float x = pk_mag[i];
         if (x <= lo) ++c_le; else mn = min(mn, __float_as_uint(x));
       }
@@ -1298,7 +1353,10 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     }
     if (tid < kTunings) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < npk; i += NT)
+#pragma unroll
+    for (int j = 0; j < KR; ++j)
+      if (tid + j * NT < npk && rmag[j] >= thr) atomicAdd(&hist[rbin[j]], 1);
+    for (int i = tid + KR * NT; i < npk; i += NT)
       if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
     __syncthreads();
     int best = 0, bcnt = hist[0];
