@@ -1359,10 +1359,13 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     for (int i = tid + KR * NT; i < npk; i += NT)
       if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
     __syncthreads();
-    int best = 0, bcnt = hist[0];
-    for (int i = 1; i < kTunings; ++i)
-      if (hist[i] > bcnt) { bcnt = hist[i]; best = i; }
-    tune = best;
+    // first maximum of the histogram: every wave reduces keys (count << 8 | 255 - bin) over its lanes (bins l and l + 64)
+    static_assert(kTunings <= 128, "two bins per lane");
+    unsigned key = ((unsigned)hist[lane] << 8) | (unsigned)(255 - lane);
+    if (lane + 64 < kTunings) key = max(key, ((unsigned)hist[lane + 64] << 8) | (unsigned)(255 - (lane + 64)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
+    tune = 255 - (int)(key & 255u);
   }
   if (tid == 0 && a.tuning) a.tuning[clip] = tune;
   if (!a.pooled) return;
