@@ -309,7 +309,9 @@ int32_t dysf_clean_create(int32_t device, int32_t sr, double prop_decrease, doub
     for (int i = 0; i <= n; ++i) v.push_back(i == n + 1 ? 0.0 : 1.0 + i * (-1.0 / (n + 1)));   // 1 + i * step, step = -1 / (n + 1)
     return v;
   };
-  const std::vector<double> wf = triangle(ngf), wt = triangle(ngt);
+  // (n_grad_freq == 1 and n_grad_time == 1 switches the smoothing off in noisereduce: a single unit tap here)
+  const bool smooth = !(ngf == 1 && ngt == 1);
+  const std::vector<double> wf = smooth ? triangle(ngf) : std::vector<double>{1.0}, wt = smooth ? triangle(ngt) : std::vector<double>{1.0};
   c->nf = (int)wf.size(); c->nt = (int)wt.size();
   double tot = 0.0;
   for (double a : wf) for (double b2 : wt) tot += a * b2;
