@@ -24,8 +24,11 @@ Workloads (BASELINE.json `configs`):
 
 A step = one pass of the hot path over the rank's resident batch.  Steps are independent batches, so they alternate
 between `--lanes` HIP streams (rsd_amd.pipeline.LaneExecutor, default 3, one extractor handle each); all lanes are joined
-before the closing fence.  Exactly W untimed warm-up steps run first (no hidden extra launches), then K timed steps between
-barrier + synchronize fences; the slowest rank's wall time counts.
+before the closing fence.  Order of a run: CPU baseline (host only), then -- at N = 1 with the default workload -- the
+PCIe-inclusive streaming measurement and the device copy-bandwidth probe (both reported, `config.before_warmup`; they also
+bring a cold GPU to its working clocks), then exactly W untimed warm-up steps of the timed workload, then K timed steps
+between barrier + synchronize fences; the slowest rank's wall time counts.  The per-kernel timing launches and the one-stream
+figure come after the timed region.
 
 Rank 0 prints ONE JSON line: the metric, a `roofline` object for the dominant kernel (durations from HIP events on the launch
 stream, bytes = SURVEY 8d's algorithmic figure, no intermediates) and, at N = 1, a `cpu_baseline` object (the NumPy oracle
@@ -298,6 +301,43 @@ def main():
             return res
         return lanes.submit(pcm, offsets, N_SAMPLES, after=after, **kw)
 
+    # The two measurements that do not belong to the timed workload run FIRST (reported in the JSON, listed in
+    # config.before_warmup): the PCIe-inclusive streaming rate and the device copy-bandwidth probe.  The timed region then
+    # starts on a GPU that is already at its working clocks -- with --warmup 5 alone the first ~50 steps of a cold process run
+    # 15-20 % slower (W 5 / K 20: 4.15 M clips/s, W 200 / K 20: 4.89 M on the same box), which says nothing about the kernels.
+    # PCIe-inclusive rate (N = 1): host int16 -> H2D overlapped with the kernels -> pooled rows back on the host
+    host_rate = None
+    if world == 1 and not args.no_host_rate and args.config == 2 and cnn is None:
+        from rsd_amd.ingest import StreamingExtractor, pinned_empty
+        n_host = 32768   # 3.1 GB of int16 PCM: the pipeline's fill (first chunk's copy, not overlapped) is 1/16 of the run
+        hoff = np.arange(n_host + 1, dtype=np.int64) * N_SAMPLES
+        host_rate = {"clips": n_host}
+        # (i) the producer decodes into page-locked memory (pinned_empty): H2D starts straight from it;
+        # (ii) an ordinary pageable array, page-locked for the call by hipHostRegister (its cost is inside the time)
+        for name, flat in (("pinned_source", pinned_empty(n_host * N_SAMPLES)), ("registered_pageable_source", np.empty(n_host * N_SAMPLES, np.int16))):
+            flat.reshape(n_host // BATCH, -1)[:] = bank.reshape(1, -1)
+            se = StreamingExtractor(ex, chunk_clips=2048)
+            se.run(flat[: 4096 * N_SAMPLES], hoff[:4097])
+            th = time.perf_counter()
+            o2 = se.run(flat, hoff)
+            th = time.perf_counter() - th
+            assert int(np.abs(o2["status"]).sum()) == 0
+            host_rate[name] = {"clips_per_s": round(n_host / th, 1), "pcm_gb_per_s": round(n_host * N_SAMPLES * 2 / th / 1e9, 2),
+                               "h2d_gb_per_s_on_the_copy_stream": round(se.h2d_gbs, 2) if se.h2d_gbs else None, "path": se.describe()}
+            del flat
+        host_rate["clips_per_s"] = host_rate["pinned_source"]["clips_per_s"]
+    # measured device-to-device copy rate (report the fraction of the measured copy bandwidth too)
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    b1.record()
+    torch.cuda.synchronize(dev)
+    copy_gbs = 5 * 2 * src.numel() * 4 / (b0.elapsed_time(b1) * 1e-3) / 1e9
+    del src, dst
     per_kernel = []
     with torch.no_grad():
         lanes.fork()
@@ -363,18 +403,6 @@ def main():
             c1.record()
             torch.cuda.synchronize(dev)
             cnn_ms = c0.elapsed_time(c1) / 10
-        # measured device-to-device copy rate (report the fraction of the measured copy bandwidth too)
-        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        b1.record()
-        torch.cuda.synchronize(dev)
-        copy_gbs = 5 * 2 * src.numel() * 4 / (b0.elapsed_time(b1) * 1e-3) / 1e9
-        del src, dst
         # configs[3]: the gathered arg-max must equal the single-GPU result of the same clips (clip j = bank clip j mod 1024)
         argmax_ok = None
         if args.config == 4:
@@ -382,27 +410,6 @@ def main():
             got = all_logits.argmax(dim=1)
             argmax_ok = bool(torch.equal(got, ref[torch.arange(total, device=dev) % BATCH]))
             assert argmax_ok, "gathered arg-max differs from the single-GPU result"
-        # PCIe-inclusive rate (N = 1): host int16 -> H2D overlapped with the kernels -> pooled rows back on the host
-        host_rate = None
-        if world == 1 and not args.no_host_rate and args.config == 2 and cnn is None:
-            from rsd_amd.ingest import StreamingExtractor, pinned_empty
-            n_host = 32768   # 3.1 GB of int16 PCM: the pipeline's fill (first chunk's copy, not overlapped) is 1/16 of the run
-            hoff = np.arange(n_host + 1, dtype=np.int64) * N_SAMPLES
-            host_rate = {"clips": n_host}
-            # (i) the producer decodes into page-locked memory (pinned_empty): H2D starts straight from it;
-            # (ii) an ordinary pageable array, page-locked for the call by hipHostRegister (its cost is inside the time)
-            for name, flat in (("pinned_source", pinned_empty(n_host * N_SAMPLES)), ("registered_pageable_source", np.empty(n_host * N_SAMPLES, np.int16))):
-                flat.reshape(n_host // BATCH, -1)[:] = bank.reshape(1, -1)
-                se = StreamingExtractor(ex, chunk_clips=2048)
-                se.run(flat[: 4096 * N_SAMPLES], hoff[:4097])
-                th = time.perf_counter()
-                o2 = se.run(flat, hoff)
-                th = time.perf_counter() - th
-                assert int(np.abs(o2["status"]).sum()) == 0
-                host_rate[name] = {"clips_per_s": round(n_host / th, 1), "pcm_gb_per_s": round(n_host * N_SAMPLES * 2 / th / 1e9, 2),
-                                   "h2d_gb_per_s_on_the_copy_stream": round(se.h2d_gbs, 2) if se.h2d_gbs else None, "path": se.describe()}
-                del flat
-            host_rate["clips_per_s"] = host_rate["pinned_source"]["clips_per_s"]
     assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3), (int(res["status"].abs().sum()), all_logits.shape)
     assert bool(torch.isfinite(all_logits).all())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -457,6 +464,7 @@ def main():
                        "step_gpu_ms": round(kms, 4), "parallelism": f"clip-sharded x{world}",
                        "launch": ("eager, batches alternate between %d streams" % n_lanes) if n_lanes > 1 else "eager, one stream",
                        "from_host": host_rate,
+                       "before_warmup": ["from_host streaming measurement (2 x 32768 clips)" if host_rate else None, "device copy-bandwidth probe (6 x 1 GiB)"],
                        "pcie_ceiling_clips_per_s": round(63e9 / (2 * N_SAMPLES), 1)},
             # HBM is the roofline SURVEY 8d prices this path against: bytes = PCM read once + outputs written once (no
             # intermediates), time = the feature launch's kernels back to back on one stream.  The kernels are NOT bandwidth
