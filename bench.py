@@ -27,8 +27,9 @@ between `--lanes` HIP streams (rsd_amd.pipeline.LaneExecutor, default 3, one ext
 before the closing fence.  Order of a run: CPU baseline (host only), then -- at N = 1 with the default workload -- the
 PCIe-inclusive streaming measurement and the device copy-bandwidth probe (both reported, `config.before_warmup`; they also
 bring a cold GPU to its working clocks), then exactly W untimed warm-up steps of the timed workload, then K timed steps
-between barrier + synchronize fences; the slowest rank's wall time counts.  The per-kernel timing launches and the one-stream
-figure come after the timed region.
+between barrier + synchronize fences; the slowest rank's wall time counts.  After the timed region: the same loop once more on
+the by then warm GPU (`config.steady_state`: both feature kernels run ~14 % faster after the first ~100 launches of a
+process -- reported next to `value`, never instead of it), the one-stream figure and the per-kernel timing launches.
 
 Rank 0 prints ONE JSON line: the metric, a `roofline` object for the dominant kernel (durations from HIP events on the launch
 stream, bytes = SURVEY 8d's algorithmic figure, no intermediates) and, at N = 1, a `cpu_baseline` object (the NumPy oracle
@@ -114,6 +115,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 with --config 4)")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state re-measurement after the timed region")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="2 = BASELINE configs[1] (1024 clips per GPU, weak scaling); 4 = configs[3] (100k clips, strong scaling); "
                          "5 = configs[4] (1-10 s clips at 22.05 kHz in 10 length buckets, 128 mels, float16-MFMA CNN head)")
@@ -358,6 +360,28 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         all_logits = res["all_logits"]
+        # for transparency: the same loop again, now that the GPU has been running this workload for a while (both feature
+        # kernels get ~14 % faster over the first ~100 launches of a process, tools/ramp.py).  Reported as
+        # config.steady_state, never as `value`.
+        steady = None
+        if args.config == 2 and not args.no_steady:
+            n_steady = max(200, args.steps)
+            lanes.fork()
+            for _ in range(n_steady):   # (its own warm-up)
+                step()
+            lanes.join()
+            fence()
+            ts0 = time.perf_counter()
+            lanes.fork()
+            for _ in range(n_steady):
+                step()
+            lanes.join()
+            fence()
+            ts = torch.tensor([time.perf_counter() - ts0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            steady = {"steps": n_steady, "ms_per_step": round(float(ts.item()) / n_steady * 1e3, 4),
+                      "clips_per_s": round(total * n_steady / float(ts.item()), 1)}
         # for transparency: the same step strictly serially on one stream (outside the timed region, not `value`)
         serial_ms = None
         if n_lanes > 1 and args.config == 2:
@@ -464,6 +488,7 @@ def main():
                        "step_gpu_ms": round(kms, 4), "parallelism": f"clip-sharded x{world}",
                        "launch": ("eager, batches alternate between %d streams" % n_lanes) if n_lanes > 1 else "eager, one stream",
                        "from_host": host_rate,
+                       "steady_state": steady,
                        "before_warmup": ["from_host streaming measurement (2 x 32768 clips)" if host_rate else None, "device copy-bandwidth probe (6 x 1 GiB)"],
                        "pcie_ceiling_clips_per_s": round(63e9 / (2 * N_SAMPLES), 1)},
             # HBM is the roofline SURVEY 8d prices this path against: bytes = PCM read once + outputs written once (no
