@@ -114,7 +114,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 with --config 4)")
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 100, 10 with --config 4: the core clock needs ~100 launches of this workload to settle, tools/ramp.py)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state re-measurement after the timed region")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="2 = BASELINE configs[1] (1024 clips per GPU, weak scaling); 4 = configs[3] (100k clips, strong scaling); "
@@ -164,6 +164,8 @@ def main():
         sys.exit(launch_ranks(args))
     if args.steps is None:
         args.steps = 20 if args.config == 4 else 200
+    if args.warmup is None:
+        args.warmup = 10 if args.config == 4 else 100
 
     import numpy as np
     import torch
