@@ -70,6 +70,10 @@ struct DysfHandle {
   hipStream_t ws_stream = nullptr;
   DevBuf d_mel_sched, d_mel_spack;  // kernel A's per-wave mel schedule and the taps laid out in its order
   int mel_slots = 0;
+  // kernel A2 (wave-private STFT + mel): block schedule of the 4x4x1 mel product
+  DevBuf d_mel4_pack, d_mel4_kbeg;
+  int mel4_steps = 0, mel4_rounds = 0;
+  int stft_variant = 0;  // DYSF_STFT: 0 choose (A2 where it applies), 1 always kernel A, 2 same as 0
 };
 
 template <typename T>
@@ -111,6 +115,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   h->device = device;
   if (const char* e = std::getenv("DYSF_DCT64")) h->dct64 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DYSF_WS_MB")) { if (std::atoll(e) > 0) h->ws_budget = (size_t)std::atoll(e) << 20; }
+  if (const char* e = std::getenv("DYSF_STFT")) h->stft_variant = std::atoi(e);
   if (device >= 0) {
     int rc = 0;
     hipError_t e = hipSetDevice(device);
@@ -158,6 +163,7 @@ void dysf_destroy(DysfHandle* h) {
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
+    h->d_mel4_pack.release(); h->d_mel4_kbeg.release();
     for (int i = 0; i < 4; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   }
   delete h;
@@ -269,6 +275,68 @@ static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::v
 }
 
 // ------------------------------------------------------------------------------------------------
+// Kernel A2's mel product (v_mfma_f32_4x4x1_16B_f32): block b of round rd owns the mels 64 rd + 4 b .. + 3 and walks the
+// bins kbeg .. kbeg + steps of its four frames' spectrum rows, 16 bytes (four K-steps) per LDS read.  All blocks take the
+// same number of steps (the longest band's); taps outside a block's band are zero.  A block's start may move down by up
+// to three 16-byte slots so that the four blocks sharing a ds_read_b128 lane group start in different slots modulo 4
+// (rows are kA2Kpad = 272 floats apart: the four frames of a block then cover one residue class of slots each).
+static void build_mel4(const HostTables& t, std::vector<float>& pack, std::vector<int32_t>& kbeg, int* steps_out, int* rounds_out) {
+  const int n_mels = t.p.n_mels, n_bins = t.n_bins;
+  const int rounds = (n_mels + 63) / 64;
+  std::vector<int> lo(rounds * 16, 0), hi(rounds * 16, 0);
+  for (int rd = 0; rd < rounds; ++rd)
+    for (int b = 0; b < 16; ++b) {
+      int l = n_bins, h = 0;
+      for (int i = 0; i < 4; ++i) {
+        const int m = 64 * rd + 4 * b + i;
+        if (m >= n_mels) continue;
+        for (int k = 0; k < n_bins; ++k)
+          if (t.mel[(size_t)m * n_bins + k] != 0.f) { l = std::min(l, k); h = std::max(h, k + 1); }
+      }
+      if (l >= h) { l = 0; h = 0; }
+      lo[rd * 16 + b] = l; hi[rd * 16 + b] = h;
+    }
+  kbeg.assign(rounds * 16, 0);
+  static const int groups[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};  // ds_read_b128 lane groups, as blocks
+  for (int rd = 0; rd < rounds; ++rd)
+    for (int g = 0; g < 4; ++g) {
+      int best_sh[4] = {0, 0, 0, 0};
+      long best_cost = -1;
+      for (int code = 0; code < 256; ++code) {
+        int sh[4], kb[4], used = 0, conflicts = 0, maxlen = 0, sum = 0;
+        bool ok = true;
+        for (int j = 0; j < 4; ++j) {
+          sh[j] = (code >> (2 * j)) & 3;
+          const int b = rd * 16 + groups[g][j];
+          kb[j] = (lo[b] & ~3) - 4 * sh[j];
+          if (kb[j] < 0) { ok = false; break; }
+          const int slot = (kb[j] >> 2) & 3;
+          if (used & (1 << slot)) ++conflicts;
+          used |= 1 << slot;
+          maxlen = std::max(maxlen, hi[b] - kb[j]);
+          sum += hi[b] - kb[j];
+        }
+        if (!ok) continue;
+        const long cost = ((long)maxlen << 24) + ((long)conflicts << 16) + sum;   // never lengthen the longest band
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; for (int j = 0; j < 4; ++j) best_sh[j] = sh[j]; }
+      }
+      for (int j = 0; j < 4; ++j) { const int b = rd * 16 + groups[g][j]; kbeg[b] = (lo[b] & ~3) - 4 * best_sh[j]; }
+    }
+  int steps = 4;
+  for (int i = 0; i < rounds * 16; ++i) steps = std::max(steps, (hi[i] - kbeg[i] + 3) & ~3);
+  for (int i = 0; i < rounds * 16; ++i) kbeg[i] = std::min(kbeg[i], (kA2Kpad - steps) & ~3);  // reads stay inside the frame's row slot
+  pack.assign((size_t)rounds * steps * 64, 0.f);
+  for (int rd = 0; rd < rounds; ++rd)
+    for (int s4 = 0; s4 < steps / 4; ++s4)
+      for (int l = 0; l < 64; ++l)
+        for (int u = 0; u < 4; ++u) {
+          const int b = l >> 2, i = l & 3, m = 64 * rd + 4 * b + i, k = kbeg[rd * 16 + b] + 4 * s4 + u;
+          if (m < n_mels && k >= 0 && k < n_bins) pack[(((size_t)rd * (steps / 4) + s4) * 64 + l) * 4 + u] = t.mel[(size_t)m * n_bins + k];
+        }
+  *steps_out = steps; *rounds_out = rounds;
+}
+
+// ------------------------------------------------------------------------------------------------
 static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t* d_offsets, int n_clips,
                    int64_t max_samples, float* d_pooled, float* d_frames, int64_t frame_stride, int32_t* d_status,
                    int32_t* d_tuning, float* dbg_S, float* dbg_logmel, hipStream_t stream, float* d_metrics = nullptr) {
@@ -301,6 +369,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.chroma_pack = h->d_chroma_pack; a.chroma_groups = t.chroma_groups;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
   a.cand_cap = std::max(4096, 16 * ((t.pip_kmax - t.pip_kmin) / 2 + 2));   // 64 KB of LDS, or one round (16 frames) if that is more
+  if (p.chroma && (size_t)a.cand_cap * 16 + 4096 > h->lds_limit)   // (+ the chroma kernel's static LDS)
+    return fail(DYSF_E_INVALID, "pitch band too wide for the chroma kernel's LDS candidate list (sr too low for this n_fft)");
 
   // ---- kernel A geometry: small workgroups, several per CU
   const int nt_a = stft_threads(t.NC), nw_a = nt_a / 64;
@@ -335,6 +405,32 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   size_t lds_a = (size_t)(lds_a_tables + tables_a) * 4;
   if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
   if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
+
+  // ---- kernel A2 (wave-private STFT + mel): the throughput presets at n_fft 512
+  const bool use_a2 = h->stft_variant != 1 && p.n_fft == 512 && !p.parity && !p.chroma && !dbg_S && !d_metrics &&
+                      p.hop <= 4096;
+  int a2_qpw = 0, a2_groups = 0;
+  size_t lds_a2 = 0;
+  if (use_a2) {
+    if (!h->mel4_steps) {
+      std::vector<float> pack; std::vector<int32_t> kb;
+      build_mel4(t, pack, kb, &h->mel4_steps, &h->mel4_rounds);
+      if (int rc = h->d_mel4_pack.reserve(pack.size() * 4)) return rc;
+      HIPCHK(hipMemcpy(h->d_mel4_pack.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice));
+      if (int rc = h->d_mel4_kbeg.reserve(kb.size() * 4)) return rc;
+      HIPCHK(hipMemcpy(h->d_mel4_kbeg.p, kb.data(), kb.size() * 4, hipMemcpyHostToDevice));
+    }
+    a.mel4_pack = (const float*)h->d_mel4_pack.p; a.mel4_kbeg = (const int*)h->d_mel4_kbeg.p;
+    a.mel4_steps = h->mel4_steps; a.mel4_rounds = h->mel4_rounds;
+    // a wave walks ~19 consecutive quads (a 3 s clip at hop 160 is one workgroup); longer clips take more workgroups
+    a2_qpw = 19;
+    if (const char* e = std::getenv("DYSF_QUADS")) { if (std::atoi(e) > 0) a2_qpw = std::atoi(e); }
+    const int64_t nq_max = (t_max + 3) / 4;
+    a2_groups = (int)((nq_max + 4 * a2_qpw - 1) / (4 * a2_qpw));
+    a.quads_per_wave = a2_qpw;
+    lds_a2 = (size_t)(4 * kA2Region + 1284 + h->mel4_rounds * h->mel4_steps * 64) * 4;
+    if (lds_a2 > h->lds_limit) return fail(DYSF_E_INVALID, "mel bands too wide for kernel A2's LDS table");
+  }
 
   // ---- kernel D geometry (rich presets: its own float32 STFT pass): 512 threads, one workgroup per clip
   const int nw_c = 8, fpi_c = t.FPW * nw_c, cb_c = (fpi_c + 15) / 16;
@@ -420,7 +516,12 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.rstride = rstride;
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
-    HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
+    if (use_a2) {
+      a.lds_region = 0; a.lds_tables = 4 * kA2Region; a.lds_misc = 4 * kA2Region + 1284; a.lds_pcm = 0;
+      HIPCHK(launch_stft_mel_wave(a, pcm_type, dim3(a2_groups, nc), lds_a2, stream));
+    } else {
+      HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
+    }
     if (h->timing) HIPCHK(hipEventRecord(h->tev[1], stream));
     HIPCHK(launch_mfcc(a, dim3(nc), lds_b, stream));
     h->ws_clean = a.self_clean != 0; h->ws_stream = stream;

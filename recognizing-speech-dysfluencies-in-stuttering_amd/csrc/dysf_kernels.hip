@@ -17,6 +17,9 @@
 //   dysf_metrics_kernel   (metrics launches, pipeline1.py:151-174) snr_db and the mean spectral flatness
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <vector>
+
 #include "dysf_fft.hpp"
 #include "dysf_kernels.h"
 
@@ -821,6 +824,193 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
     for (int w = 1; w < NW; ++w) m = fmaxf(m, misc[w]);
     atomicMax(a.ws_clipmax + clip, __float_as_uint(fmaxf(m, 0.f)));  // non-negative floats order like their bits
   }
+}
+
+// =============================================================================================
+// Kernel A2: the same PCM -> STFT power -> mel -> dB pass for the throughput presets (n_fft 512, no chroma, no parity
+// arithmetic), with nothing shared between the waves of a workgroup but read-only tables: no barrier after start-up.
+//   * a wave owns a run of frame quads (four consecutive frames, 16 lanes x 16 complex points each) of one clip;
+//   * PCM goes straight from global memory into the registers of the lane that transforms it (one 4-byte load per
+//     complex point, the next quad's loads in flight during this quad's FFT): no LDS tile, no commit pass;
+//   * the FFT is kernel A's (radix 16 x 16, one transpose through the wave's LDS region, DPP un-packing);
+//   * the four spectrum rows overwrite the exchange buffer, and the mel product runs on v_mfma_f32_4x4x1_16B_f32:
+//     sixteen independent 4 x 4 blocks, block b = mels 4b .. 4b+3 against the wave's own four frames, every block
+//     walking its own band of bins (host-built: KArgs::mel4_*), both operands read 16 bytes at a time;
+//   * 10 log10, one 16-byte store per lane into the frame-major log-mel workspace, running max of the mel power.
+// grid = (wave groups, clips), 256 threads; wave w of workgroup g takes quads [(4g + w) * quads_per_wave, ...).
+template <int PCM>
+struct QuadPcm { int v[PCM == DYSF_PCM_I16 ? 16 : 32]; };
+
+// 4-byte-per-lane loads of sample pairs; a clip may start at an odd sample of the flat buffer (2-byte alignment)
+typedef int i32_a2 __attribute__((aligned(2)));
+typedef int i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int PCM>
+__device__ __forceinline__ void quad_prefetch(QuadPcm<PCM>& st, const char* pbase, int n, int T, int hop, int f0, int q, int ls) {
+  constexpr int NC = 256;
+  const int s_t = (f0 + q) * hop - NC;  // first sample of this lane's frame (centre padding: may be negative)
+  // wave-uniform: all four frames lie inside the clip (true for all but the first and the last one or two quads)
+  if (f0 * hop - NC >= 0 && (f0 + 3) * hop + NC <= n) {
+    if (PCM == DYSF_PCM_I16) {
+      const char* p0 = pbase + 2 * (s_t + 2 * ls);
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) st.v[p] = *(const i32_a2*)(p0 + 64 * p);
+    } else {
+      const char* p0 = pbase + 4 * (s_t + 2 * ls);
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) {
+        const i32x2_a4 w = *(const i32x2_a4*)(p0 + 128 * p);
+        st.v[2 * p] = w[0]; st.v[2 * p + 1] = w[1];
+      }
+    }
+    return;
+  }
+  const bool live = f0 + q < T;
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    const int i0 = s_t + 2 * (ls + 16 * p);
+    const bool in0 = live && i0 >= 0 && i0 < n, in1 = live && i0 + 1 >= 0 && i0 + 1 < n;
+    if (PCM == DYSF_PCM_I16) {
+      const unsigned short* b = (const unsigned short*)pbase;
+      const unsigned lo = in0 ? (unsigned)b[i0] : 0u, hi = in1 ? (unsigned)b[i0 + 1] : 0u;
+      st.v[p] = (int)(lo | (hi << 16));
+    } else {
+      const int* b = (const int*)pbase;
+      st.v[2 * p] = in0 ? b[i0] : 0;
+      st.v[2 * p + 1] = in1 ? b[i0 + 1] : 0;
+    }
+  }
+}
+
+template <int PCM>
+__global__ __launch_bounds__(256, 4) void dysf_stft_mel_wave_kernel(const KArgs a) {
+  constexpr int NC = 256;
+  using G = FftGeom<NC>;
+  constexpr int L = G::L;
+  static_assert(L == 16 && G::FPW == 4 && G::XSTRIDE == kA2Kpad, "kernel A2 is laid out for n_fft 512");
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, ls = lane & 15;   // FFT roles: frame of the quad, lane of the frame
+  const int mb = lane >> 2, mr = lane & 3;   // mel roles: block (four mels), A row / B column (mel of the block / frame)
+  const int clip = blockIdx.y;
+  const long long off = a.offsets[clip];
+  const long long n64 = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n64 / a.hop);
+  if (n64 <= 0 || T < 9 || T > a.t_max) return;  // rejected clips: kernel B writes their zero rows
+  const int n = (int)n64;
+  const int NQ = (T + 3) >> 2;
+  if (blockIdx.x * 4 * a.quads_per_wave >= NQ) return;  // whole workgroup beyond the clip
+
+  float* wregion = lds + a.lds_region + wave * kA2Region;
+  cf* win = (cf*)(lds + a.lds_tables);                       // [NC] (w[2n], w[2n+1]) / 2 (x 2^-15 for int16 PCM)
+  cf* ptw = (cf*)(lds + a.lds_tables + 2 * NC);              // [NC/2 + 1] un-packing twiddles
+  cf* t1s = (cf*)(lds + a.lds_tables + 2 * NC + 260);        // [16][L] stage-1 twiddles, point-major
+  float* melA = lds + a.lds_misc;                            // [rounds][steps/4][64][4]
+  {
+    const float* wsrc = (PCM == DYSF_PCM_I16) ? a.window_i16 : a.window;
+    for (int i = tid; i < 2 * NC; i += 256) ((float*)win)[i] = wsrc[i];
+    for (int i = tid; i < NC + 2; i += 256) ((float*)ptw)[i] = a.post_tw[i];
+    for (int i = tid; i < kPts * L; i += 256) t1s[i] = ((const cf*)a.stage_tw)[(i % L) * kPts + (i / L)];
+    const int nm = a.mel4_rounds * a.mel4_steps * 16;        // float4 count
+    for (int i = tid; i < nm; i += 256) ((float4*)melA)[i] = ((const float4*)a.mel4_pack)[i];
+    // the mel product reads a few words past a row's last bin and the exchange leaves one word per frame untouched
+    for (int i = lane * 4; i < kA2Region; i += 256) *(float4*)(wregion + i) = float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();  // the only barrier: tables are in place
+
+  const int q_begin = (blockIdx.x * 4 + wave) * a.quads_per_wave;
+  const int q_end = min(NQ, q_begin + a.quads_per_wave);
+  if (q_begin >= q_end) return;
+  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
+  float* xb = wregion + q * G::XSTRIDE;
+  float* srow_own = wregion + q * kA2Kpad;
+  float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
+  const int steps4 = a.mel4_steps >> 2;
+  int kbeg_r[2];  // first bin of this lane's block, per round (at most two rounds: n_mels <= 128)
+  kbeg_r[0] = a.mel4_kbeg[mb];
+  kbeg_r[1] = a.mel4_rounds > 1 ? a.mel4_kbeg[16 + mb] : 0;
+  const unsigned long long lane0 = __ballot(ls == 0);
+  float lmax = 0.f;
+  float badacc = 0.f;  // float PCM: x * 0 summed over every sample is NaN iff one of them is not finite
+
+  QuadPcm<PCM> st;
+  quad_prefetch<PCM>(st, pbase, n, T, a.hop, 4 * q_begin, q, ls);
+  for (int qi = q_begin; qi < q_end; ++qi) {
+    const int f0 = 4 * qi;
+    cf z[kPts];
+#pragma unroll
+    for (int p = 0; p < kPts; ++p) {
+      cf x;
+      if (PCM == DYSF_PCM_I16) {
+        x[0] = (float)(short)(st.v[p] & 0xffff); x[1] = (float)(st.v[p] >> 16);
+      } else {
+        x[0] = __int_as_float(st.v[2 * p]); x[1] = __int_as_float(st.v[2 * p + 1]);
+        badacc = fmaf(x[0], 0.f, badacc); badacc = fmaf(x[1], 0.f, badacc);
+      }
+      z[p] = x * win[ls + L * p];
+    }
+    if (qi + 1 < q_end) quad_prefetch<PCM>(st, pbase, n, T, a.hop, f0 + 4, q, ls);  // in flight during this quad's FFT
+    fft_stage<NC, 0>(z, (const cf*)nullptr);
+    fft_exchange<NC, 0>(z, xb, ls);
+    {
+      cf t1[kPts];
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) t1[p] = t1s[p * L + ls];
+      fft_stage<NC, 1>(z, t1);
+    }
+    // un-packing: register p of lane ls holds Z[ls + 16 p]; Z[NC - k] sits in register 15 - i of lane 16 - ls (lane 0
+    // pairs with itself, one register on): row_mirror + row_ror:1, as in kernel A
+    cf zm[9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float offer;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
+        const int m = __builtin_amdgcn_mov_dpp(__float_as_int(offer), 0x140, 0xf, 0xf, true);
+        zm[i][h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
+      }
+    }
+    zm[8] = z[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = (i == 8) ? NC / 2 : ls + L * i;
+      float pk, pm;
+      rfft_pair_power(z[i], zm[i], ptw[k], &pk, &pm);
+      if (i < 8 || ls == 0) {
+        srow_own[k] = pk;
+        srow_own[NC - k] = pm;
+      }
+    }
+    wave_lds_sync();
+    // mel product: D_b[4 mels x 4 frames] += A_b[4 x 1] * B_b[1 x 4] per K-step, the sixteen blocks in one instruction
+    for (int rd = 0; rd < a.mel4_rounds; ++rd) {
+      const float4* Ap = (const float4*)melA + (size_t)rd * steps4 * 64 + lane;
+      const float4* Bp = (const float4*)(wregion + mr * kA2Kpad + (rd ? kbeg_r[1] : kbeg_r[0]));
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int s = 0; s < steps4; ++s) {
+        const float4 av = Ap[s * 64], bv = Bp[s];
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+      // lane (block mb, column mr) holds mels 64 rd + 4 mb + {0..3} of frame f0 + mr
+      const int t = f0 + mr, m0 = 64 * rd + 4 * mb;
+      if (t < T && m0 < a.lm_stride) {
+        float4 v;
+        v.x = power_to_db(acc[0], a); v.y = power_to_db(acc[1], a); v.z = power_to_db(acc[2], a); v.w = power_to_db(acc[3], a);
+        *(float4*)(lm + (size_t)t * a.lm_stride + m0) = v;
+        lmax = fmaxf(fmaxf(lmax, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      }
+    }
+    wave_lds_sync();
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) atomicMax(a.ws_clipmax + clip, __float_as_uint(fmaxf(lmax, 0.f)));
+  if (PCM == DYSF_PCM_F32 && !(badacc == 0.f)) a.ws_flags[clip] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1706,18 +1896,29 @@ __global__ __launch_bounds__(NT) void dysf_metrics_kernel(const KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename K>
-static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
-  // the attribute is raised once per kernel (and again only if a later launch needs more): steady-state launches are
-  // pure stream work and can be captured into a hipGraph by the caller
-  static size_t granted[64] = {};  // per device; one instance per template instantiation (a handle is single-threaded)
+// The dynamic-LDS attribute belongs to the kernel function (per device), not to a handle or a template instantiation of
+// this helper: one process-wide table keyed by function and device, only ever raised.  Steady-state launches are pure
+// stream work and can be captured into a hipGraph by the caller.
+static hipError_t grant_dynamic_lds(const void* kern, size_t lds_bytes) {
+  struct Entry { const void* fn; int dev; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> table;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  size_t& have = granted[dev & 63];
-  if (lds_bytes > have) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (Entry& x : table) if (x.fn == kern && x.dev == dev) { e = &x; break; }
+  if (e && lds_bytes <= e->bytes) return hipSuccess;
+  const hipError_t rc = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (rc != hipSuccess) return rc;
+  if (e) e->bytes = lds_bytes; else table.push_back({kern, dev, lds_bytes});
+  return hipSuccess;
+}
+template <typename K>
+static hipError_t launch_one(K kern, dim3 grid, int threads, size_t lds_bytes, hipStream_t s, const KArgs& a) {
+  if (lds_bytes > 0) {
+    const hipError_t e = grant_dynamic_lds((const void*)kern, lds_bytes);
     if (e != hipSuccess) return e;
-    have = lds_bytes;
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, s, a);
   return hipGetLastError();
@@ -1763,6 +1964,10 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
     default: return hipErrorInvalidValue;
   }
 }
+hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_I16>, grid, 256, lds_bytes, s, a);
+  return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_F32>, grid, 256, lds_bytes, s, a);
+}
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   // up to 64 mels: mean-free float32 MFMA.  The eight-group form of it spills its statistics accumulators, so the
   // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tests/diagnostics/margin.py).
@@ -1795,12 +2000,13 @@ template <int NC>
 static hipError_t launch_chroma_nc(const KArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   constexpr int NVF = (NC + 1 + 255) / 256;          // slices that cover bins 0 .. NC
   constexpr int NVS = NVF < 3 ? NVF : 3;
-  if ((a.pip_kmax + 1 + 255) / 256 <= NVS) hipLaunchKernelGGL((dysf_chroma_kernel<NC, 512, NVS>), grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((dysf_chroma_kernel<NC, 512, NVF>), grid, dim3(512), lds, s, a);
-  return hipGetLastError();
+  // (the candidate list of a wide pitch band -- low sample rates at n_fft 2048 -- exceeds the 64 KB a kernel gets without
+  // the attribute: launch_one raises it)
+  if ((a.pip_kmax + 1 + 255) / 256 <= NVS) return launch_one(dysf_chroma_kernel<NC, 512, NVS>, grid, 512, lds, s, a);
+  return launch_one(dysf_chroma_kernel<NC, 512, NVF>, grid, 512, lds, s, a);
 }
 hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s) {
-  const size_t lds = (size_t)a.cand_cap * sizeof(float4);   // <= 64 KB: no attribute needed
+  const size_t lds = (size_t)a.cand_cap * sizeof(float4);
   switch (n_fft) {
     case 256: return launch_chroma_nc<128>(a, grid, lds, s);
     case 512: return launch_chroma_nc<256>(a, grid, lds, s);
