@@ -13,6 +13,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _npz_layers(z, prefix: str = ""):
+    """(weights, biases) of a dense stack stored as <prefix>W1, <prefix>b1, <prefix>W2, ... in an .npz fixture."""
+    Ws, bs = [], []
+    while f"{prefix}W{len(Ws) + 1}" in z.files:
+        i = len(Ws) + 1
+        Ws.append(z[f"{prefix}W{i}"]); bs.append(z[f"{prefix}b{i}"])
+    if not Ws:
+        raise KeyError(f"no {prefix}W1 in the fixture")
+    return Ws, bs
+
+
 class MLPHead(nn.Module):
     """(x - mean_) / scale_  ->  relu(x W1 + b1) -> relu(. W2 + b2) -> . W3 + b3  (logits); softmax for proba."""
 
@@ -28,10 +39,12 @@ class MLPHead(nn.Module):
         self.n_features_in_ = int(np.asarray(mean).shape[0])
 
     @classmethod
-    def from_npz(cls, path: str, dtype=torch.float32) -> "MLPHead":
+    def from_npz(cls, path: str, dtype=torch.float32, prefix: str = "") -> "MLPHead":
+        """``prefix`` selects one model of a multi-model fixture (tests/golden/deployed_models.npz: "mlp_"); any number
+        of layers W1, b1, W2, b2, ... is taken (pipeline1.py:497 has two hidden layers, main1.py:863 three)."""
         z = np.load(path, allow_pickle=False)
-        return cls(z["mean"], z["scale"], [z["W1"], z["W2"], z["W3"]], [z["b1"], z["b2"], z["b3"]],
-                   classes=z["classes"], dtype=dtype)
+        Ws, bs = _npz_layers(z, prefix)
+        return cls(z["mean"], z["scale"], Ws, bs, classes=z["classes"], dtype=dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[-1] != self.n_features_in_:  # the guard of main1.py:976-981
@@ -89,10 +102,10 @@ class FusedMLPHead:
             raise _lib.DysfError(f"dysf_mlp_create failed ({rc}): {L.dysf_mlp_last_error().decode()}")
 
     @classmethod
-    def from_npz(cls, path: str, device: int = 0) -> "FusedMLPHead":
+    def from_npz(cls, path: str, device: int = 0, prefix: str = "") -> "FusedMLPHead":
         z = np.load(path, allow_pickle=False)
-        return cls(z["mean"], z["scale"], [z["W1"], z["W2"], z["W3"]], [z["b1"], z["b2"], z["b3"]],
-                   classes=z["classes"], device=device)
+        Ws, bs = _npz_layers(z, prefix)
+        return cls(z["mean"], z["scale"], Ws, bs, classes=z["classes"], device=device)
 
     def _run(self, x: torch.Tensor, logits=True, proba=False, pred=False):
         import ctypes
@@ -161,9 +174,10 @@ class RandomForestHead:
             raise _lib.DysfError(f"dysf_forest_create failed ({rc}): {L.dysf_forest_last_error().decode()}")
 
     @classmethod
-    def from_npz(cls, path: str, classes=None, device: int = 0) -> "RandomForestHead":
+    def from_npz(cls, path: str, classes=None, device: int = 0, prefix: str = "") -> "RandomForestHead":
         z = np.load(path, allow_pickle=False)
-        return cls(z["feature"], z["threshold"], z["left"], z["right"], z["value"], z["root"], z["mean"], z["scale"],
+        g = lambda k: z[prefix + k]  # noqa: E731
+        return cls(g("feature"), g("threshold"), g("left"), g("right"), g("value"), g("root"), z["mean"], z["scale"],
                    classes=classes, device=device)
 
     def _run(self, x: torch.Tensor):
@@ -234,10 +248,11 @@ class SVCHead:
             raise _lib.DysfError(f"dysf_svc_create failed ({rc}): {L.dysf_svc_last_error().decode()}")
 
     @classmethod
-    def from_npz(cls, path: str, classes=None, device: int = 0) -> "SVCHead":
+    def from_npz(cls, path: str, classes=None, device: int = 0, prefix: str = "") -> "SVCHead":
         z = np.load(path, allow_pickle=False)
-        return cls(z["support_vectors"], z["dual_coef"], z["intercept"], z["n_support"], float(z["gamma"]), z["mean"],
-                   z["scale"], z["prob_a"], z["prob_b"], classes=classes, device=device)
+        g = lambda k: z[prefix + k]  # noqa: E731
+        return cls(g("support_vectors"), g("dual_coef"), g("intercept"), g("n_support"), float(g("gamma")), z["mean"],
+                   z["scale"], g("prob_a"), g("prob_b"), classes=classes, device=device)
 
     def _run(self, x: torch.Tensor, want_proba: bool = True):
         import ctypes

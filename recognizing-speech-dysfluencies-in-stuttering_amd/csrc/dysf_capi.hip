@@ -275,65 +275,75 @@ static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::v
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A2's mel product (v_mfma_f32_4x4x1_16B_f32): block b of round rd owns the mels 64 rd + 4 b .. + 3 and walks the
-// bins kbeg .. kbeg + steps of its four frames' spectrum rows, 16 bytes (four K-steps) per LDS read.  All blocks take the
-// same number of steps (the longest band's); taps outside a block's band are zero.  A block's start may move down by up
-// to three 16-byte slots so that the four blocks sharing a ds_read_b128 lane group start in different slots modulo 4
-// (rows are kA2Kpad = 272 floats apart: the four frames of a block then cover one residue class of slots each).
-static void build_mel4(const HostTables& t, std::vector<float>& pack, std::vector<int32_t>& kbeg, int* steps_out, int* rounds_out) {
+// Kernel A2's mel product on v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 blocks per instruction (four mels against
+// the wave's four frames), one K-step (bin) each.  A group of four consecutive mels has a band of 7 (low) to 54 (high) bins
+// at 512 / 64 mels; walking every group in its own block would cost the longest band's steps.  The schedule spreads the
+// long bands over idle blocks instead -- two accumulator sets of sixteen blocks, S steps each:
+//   set 0: row r (= DPP row: blocks 4r .. 4r+3) holds the r-th longest group, its band cut into four pieces;
+//   set 1: blocks 4r, 4r+1 hold two short groups, blocks 4r+2, 4r+3 the two halves of a middle one.
+// After the products the kernel adds set 0's pieces within each row (two DPP row shifts), the halves of set 1 (one), and
+// parks the row's set-0 result in block 4r+3 of set 1: every block of set 1 then holds one finished group, out[] says
+// which.  Taps outside a slot's piece are zero; piece starts are multiples of four bins (16-byte LDS reads).
+static void build_mel4(const HostTables& t, std::vector<float>& pack, std::vector<int32_t>& meta, int* steps_out, int* rounds_out) {
   const int n_mels = t.p.n_mels, n_bins = t.n_bins;
   const int rounds = (n_mels + 63) / 64;
-  std::vector<int> lo(rounds * 16, 0), hi(rounds * 16, 0);
-  for (int rd = 0; rd < rounds; ++rd)
-    for (int b = 0; b < 16; ++b) {
+  struct Slot { int group = -1, k0 = 0, k1 = 0; };  // bins [k0, k1) of the group's band
+  std::vector<Slot> slots((size_t)rounds * 32);    // [round][set][block]
+  std::vector<int> out((size_t)rounds * 16, -1);
+  int S = 4;
+  for (int rd = 0; rd < rounds; ++rd) {
+    int lo[16], hi[16], order[16];
+    for (int g = 0; g < 16; ++g) {
       int l = n_bins, h = 0;
       for (int i = 0; i < 4; ++i) {
-        const int m = 64 * rd + 4 * b + i;
+        const int m = 64 * rd + 4 * g + i;
         if (m >= n_mels) continue;
         for (int k = 0; k < n_bins; ++k)
           if (t.mel[(size_t)m * n_bins + k] != 0.f) { l = std::min(l, k); h = std::max(h, k + 1); }
       }
       if (l >= h) { l = 0; h = 0; }
-      lo[rd * 16 + b] = l; hi[rd * 16 + b] = h;
+      lo[g] = l & ~3; hi[g] = h; order[g] = g;
     }
-  kbeg.assign(rounds * 16, 0);
-  static const int groups[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};  // ds_read_b128 lane groups, as blocks
-  for (int rd = 0; rd < rounds; ++rd)
-    for (int g = 0; g < 4; ++g) {
-      int best_sh[4] = {0, 0, 0, 0};
-      long best_cost = -1;
-      for (int code = 0; code < 256; ++code) {
-        int sh[4], kb[4], used = 0, conflicts = 0, maxlen = 0, sum = 0;
-        bool ok = true;
-        for (int j = 0; j < 4; ++j) {
-          sh[j] = (code >> (2 * j)) & 3;
-          const int b = rd * 16 + groups[g][j];
-          kb[j] = (lo[b] & ~3) - 4 * sh[j];
-          if (kb[j] < 0) { ok = false; break; }
-          const int slot = (kb[j] >> 2) & 3;
-          if (used & (1 << slot)) ++conflicts;
-          used |= 1 << slot;
-          maxlen = std::max(maxlen, hi[b] - kb[j]);
-          sum += hi[b] - kb[j];
-        }
-        if (!ok) continue;
-        const long cost = ((long)maxlen << 24) + ((long)conflicts << 16) + sum;   // never lengthen the longest band
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; for (int j = 0; j < 4; ++j) best_sh[j] = sh[j]; }
+    std::stable_sort(order, order + 16, [&](int x, int y) { return hi[x] - lo[x] > hi[y] - lo[y]; });
+    auto cut = [&](int g, int parts, int j, Slot& sl) {   // piece j of the band of group g cut into `parts` pieces
+      const int len = hi[g] - lo[g];
+      const int pl = ((len + parts - 1) / parts + 3) & ~3;
+      sl.group = g; sl.k0 = std::min(hi[g], lo[g] + j * pl); sl.k1 = std::min(hi[g], lo[g] + (j + 1) * pl);
+      S = std::max(S, (sl.k1 - sl.k0 + 3) & ~3);
+    };
+    for (int r = 0; r < 4; ++r) {
+      Slot* s0 = &slots[((size_t)rd * 2 + 0) * 16 + 4 * r];
+      Slot* s1 = &slots[((size_t)rd * 2 + 1) * 16 + 4 * r];
+      for (int j = 0; j < 4; ++j) cut(order[r], 4, j, s0[j]);          // the four longest: quarters in set 0
+      cut(order[8 + 2 * r], 1, 0, s1[0]);                              // the eight shortest: whole
+      cut(order[9 + 2 * r], 1, 0, s1[1]);
+      cut(order[4 + r], 2, 0, s1[2]); cut(order[4 + r], 2, 1, s1[3]);  // the next four: halves in set 1
+      out[rd * 16 + 4 * r] = order[8 + 2 * r]; out[rd * 16 + 4 * r + 1] = order[9 + 2 * r];
+      out[rd * 16 + 4 * r + 2] = order[4 + r]; out[rd * 16 + 4 * r + 3] = order[r];
+    }
+  }
+  // meta: [round][0..15] first bin of set 0's blocks, [16..31] of set 1's, [32..47] mel offset of the finished block (-1: none)
+  meta.assign((size_t)rounds * 48, 0);
+  pack.assign((size_t)rounds * (S / 4) * 2 * 64 * 4, 0.f);
+  for (int rd = 0; rd < rounds; ++rd) {
+    for (int set = 0; set < 2; ++set)
+      for (int b = 0; b < 16; ++b) {
+        const Slot& sl = slots[((size_t)rd * 2 + set) * 16 + b];
+        const int kb = std::min(sl.k0 & ~3, (kA2Kpad - S) & ~3);   // the S steps stay inside the frame's row slot
+        meta[rd * 48 + set * 16 + b] = kb;
+        for (int st = 0; st < S; ++st)
+          for (int i = 0; i < 4; ++i) {
+            const int k = kb + st, m = 64 * rd + 4 * sl.group + i, l = 4 * b + i;
+            if (sl.group >= 0 && m < n_mels && k >= sl.k0 && k < sl.k1)
+              pack[((((size_t)rd * (S / 4) + st / 4) * 2 + set) * 64 + l) * 4 + (st & 3)] = t.mel[(size_t)m * n_bins + k];
+          }
       }
-      for (int j = 0; j < 4; ++j) { const int b = rd * 16 + groups[g][j]; kbeg[b] = (lo[b] & ~3) - 4 * best_sh[j]; }
+    for (int b = 0; b < 16; ++b) {
+      const int g = out[rd * 16 + b];
+      meta[rd * 48 + 32 + b] = (g >= 0 && 64 * rd + 4 * g < t.mpad) ? 64 * rd + 4 * g : -1;
     }
-  int steps = 4;
-  for (int i = 0; i < rounds * 16; ++i) steps = std::max(steps, (hi[i] - kbeg[i] + 3) & ~3);
-  for (int i = 0; i < rounds * 16; ++i) kbeg[i] = std::min(kbeg[i], (kA2Kpad - steps) & ~3);  // reads stay inside the frame's row slot
-  pack.assign((size_t)rounds * steps * 64, 0.f);
-  for (int rd = 0; rd < rounds; ++rd)
-    for (int s4 = 0; s4 < steps / 4; ++s4)
-      for (int l = 0; l < 64; ++l)
-        for (int u = 0; u < 4; ++u) {
-          const int b = l >> 2, i = l & 3, m = 64 * rd + 4 * b + i, k = kbeg[rd * 16 + b] + 4 * s4 + u;
-          if (m < n_mels && k >= 0 && k < n_bins) pack[(((size_t)rd * (steps / 4) + s4) * 64 + l) * 4 + u] = t.mel[(size_t)m * n_bins + k];
-        }
-  *steps_out = steps; *rounds_out = rounds;
+  }
+  *steps_out = S; *rounds_out = rounds;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,26 +419,33 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   // ---- kernel A2 (wave-private STFT + mel): the throughput presets at n_fft 512
   const bool use_a2 = h->stft_variant != 1 && p.n_fft == 512 && !p.parity && !p.chroma && !dbg_S && !d_metrics &&
                       p.hop <= 4096;
-  int a2_qpw = 0, a2_groups = 0;
+  int a2_qpw = 0, a2_groups = 0, a2_nw = 4, a2_occ = 5;
   size_t lds_a2 = 0;
   if (use_a2) {
     if (!h->mel4_steps) {
-      std::vector<float> pack; std::vector<int32_t> kb;
-      build_mel4(t, pack, kb, &h->mel4_steps, &h->mel4_rounds);
+      std::vector<float> pack; std::vector<int32_t> meta;
+      build_mel4(t, pack, meta, &h->mel4_steps, &h->mel4_rounds);
       if (int rc = h->d_mel4_pack.reserve(pack.size() * 4)) return rc;
       HIPCHK(hipMemcpy(h->d_mel4_pack.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice));
-      if (int rc = h->d_mel4_kbeg.reserve(kb.size() * 4)) return rc;
-      HIPCHK(hipMemcpy(h->d_mel4_kbeg.p, kb.data(), kb.size() * 4, hipMemcpyHostToDevice));
+      if (int rc = h->d_mel4_kbeg.reserve(meta.size() * 4)) return rc;
+      HIPCHK(hipMemcpy(h->d_mel4_kbeg.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
     }
     a.mel4_pack = (const float*)h->d_mel4_pack.p; a.mel4_kbeg = (const int*)h->d_mel4_kbeg.p;
     a.mel4_steps = h->mel4_steps; a.mel4_rounds = h->mel4_rounds;
-    // a wave walks ~19 consecutive quads (a 3 s clip at hop 160 is one workgroup); longer clips take more workgroups
-    a2_qpw = 19;
+    if (const char* e = std::getenv("DYSF_A2_NW")) a2_nw = std::atoi(e) == 8 ? 8 : 4;
+    if (const char* e = std::getenv("DYSF_A2_OCC")) a2_occ = std::max(4, std::min(6, std::atoi(e)));
+    const int tab_floats = 16 * 84 + h->mel4_rounds * h->mel4_steps * 2 * 64;
+    lds_a2 = (size_t)(a2_nw * kA2Region + tab_floats) * 4;
+    // the occupancy the build is compiled for must fit the CU's LDS; step down otherwise (wider mel banks)
+    while (a2_occ > 4 && lds_a2 * (size_t)(4 * a2_occ / a2_nw) > h->lds_limit) --a2_occ;
+    // a wave walks ~19 consecutive quads (a 3 s clip at hop 160 is one 4-wave workgroup); longer clips take more workgroups
+    a2_qpw = a2_nw == 8 ? 10 : 19;
     if (const char* e = std::getenv("DYSF_QUADS")) { if (std::atoi(e) > 0) a2_qpw = std::atoi(e); }
     const int64_t nq_max = (t_max + 3) / 4;
-    a2_groups = (int)((nq_max + 4 * a2_qpw - 1) / (4 * a2_qpw));
+    a2_groups = (int)((nq_max + a2_nw * a2_qpw - 1) / (a2_nw * a2_qpw));
     a.quads_per_wave = a2_qpw;
-    lds_a2 = (size_t)(4 * kA2Region + 1284 + h->mel4_rounds * h->mel4_steps * 64) * 4;
+    a.stagger_mode = 0; a.stagger_units = 6;
+    if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a2 += (size_t)std::atoi(e);  // occupancy experiments only
     if (lds_a2 > h->lds_limit) return fail(DYSF_E_INVALID, "mel bands too wide for kernel A2's LDS table");
   }
 
@@ -517,8 +534,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
     if (use_a2) {
-      a.lds_region = 0; a.lds_tables = 4 * kA2Region; a.lds_misc = 4 * kA2Region + 1284; a.lds_pcm = 0;
-      HIPCHK(launch_stft_mel_wave(a, pcm_type, dim3(a2_groups, nc), lds_a2, stream));
+      a.lds_region = 0; a.lds_tables = a2_nw * kA2Region; a.lds_misc = a2_nw * kA2Region + 16 * 84; a.lds_pcm = 0;
+      HIPCHK(launch_stft_mel_wave(a, pcm_type, a2_nw, a2_occ, dim3(a2_groups, nc), lds_a2, stream));
     } else {
       HIPCHK(launch_stft_mel(a, p.n_fft, pcm_type, dim3(groups, nc), lds_a, stream));
     }

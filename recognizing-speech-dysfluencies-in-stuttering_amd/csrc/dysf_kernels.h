@@ -83,12 +83,13 @@ struct KArgs {
   // LDS carve-up (float offsets) of the kernel being launched
   int lds_region, lds_pcm, lds_misc, lds_tables;
   // kernel A2 (wave-private STFT + mel, throughput presets at n_fft 512): mel product on v_mfma_f32_4x4x1_16B_f32
-  const float* mel4_pack;  // [rounds][steps / 4][64 lanes][4] A operands: lane (block b = l >> 2, row i = l & 3) holds the
-                           // taps of mel 64*round + 4*b + i at the bins kbeg[round][b] + 4*s .. + 3
-  const int* mel4_kbeg;    // [rounds][16] first bin of every block's run of K-steps (a multiple of 4)
-  int mel4_steps;          // K-steps per round (a multiple of 4)
+  const float* mel4_pack;  // [rounds][steps / 4][2 sets][64 lanes][4] A operands: lane (block b = l >> 2, row i = l & 3) holds
+                           // the taps of its slot's mel i at the bins kbeg + 4*s .. + 3 (dysf_capi.hip: build_mel4)
+  const int* mel4_kbeg;    // [rounds][48]: first bin of set 0's blocks, of set 1's blocks, mel offset of the finished blocks
+  int mel4_steps;          // K-steps per set (a multiple of 4)
   int mel4_rounds;         // rounds of 16 blocks x 4 mels = ceil(n_mels / 64)
   int quads_per_wave;      // consecutive groups of four frames one wave transforms
+  int stagger_mode, stagger_units;  // start delay per wave (see the kernel): key source, units of 512 cycles per key step
 };
 
 constexpr int kA2Kpad = 272;      // kernel A2: floats per power-spectrum row in LDS (= the FFT exchange stride of a frame)
@@ -109,7 +110,7 @@ constexpr int kMfccHead = 144;                           // kernel B: frame-0 fe
 constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
-hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);  // kernel A2
+hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, int waves_per_wg, int waves_per_simd, dim3 grid, size_t lds_bytes, hipStream_t s);  // kernel A2
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s);
 hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s);

@@ -838,6 +838,7 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
 //     walking its own band of bins (host-built: KArgs::mel4_*), both operands read 16 bytes at a time;
 //   * 10 log10, one 16-byte store per lane into the frame-major log-mel workspace, running max of the mel power.
 // grid = (wave groups, clips), 256 threads; wave w of workgroup g takes quads [(4g + w) * quads_per_wave, ...).
+typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // volatile float in LDS (a plain volatile cast makes it a flat access)
 template <int PCM>
 struct QuadPcm { int v[PCM == DYSF_PCM_I16 ? 16 : 32]; };
 
@@ -865,25 +866,51 @@ __device__ __forceinline__ void quad_prefetch(QuadPcm<PCM>& st, const char* pbas
     }
     return;
   }
+  // edge quads: every load goes to a clamped (always valid) sample and is zeroed afterwards if its position lies outside
+  // the clip or its frame does not exist -- no divergent branches, few live registers
   const bool live = f0 + q < T;
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
     const int i0 = s_t + 2 * (ls + 16 * p);
     const bool in0 = live && i0 >= 0 && i0 < n, in1 = live && i0 + 1 >= 0 && i0 + 1 < n;
+    const int c0 = min(max(i0, 0), n - 1), c1 = min(max(i0 + 1, 0), n - 1);
     if (PCM == DYSF_PCM_I16) {
       const unsigned short* b = (const unsigned short*)pbase;
-      const unsigned lo = in0 ? (unsigned)b[i0] : 0u, hi = in1 ? (unsigned)b[i0 + 1] : 0u;
-      st.v[p] = (int)(lo | (hi << 16));
+      const unsigned lo = b[c0], hi = b[c1];
+      st.v[p] = (int)((in0 ? lo : 0u) | ((in1 ? hi : 0u) << 16));
     } else {
       const int* b = (const int*)pbase;
-      st.v[2 * p] = in0 ? b[i0] : 0;
-      st.v[2 * p + 1] = in1 ? b[i0 + 1] : 0;
+      const int lo = b[c0], hi = b[c1];
+      st.v[2 * p] = in0 ? lo : 0;
+      st.v[2 * p + 1] = in1 ? hi : 0;
     }
   }
 }
 
-template <int PCM>
-__global__ __launch_bounds__(256, 4) void dysf_stft_mel_wave_kernel(const KArgs a) {
+// Un-packing of one bin pair (k, NC - k) straight to the two powers: zk = Z[k], zm = Z[NC - k], v = V[k] (see
+// rfft_pair_power).  Eight packed instructions: the conjugations ride on neg modifiers, and X = e + t, Y = e - t are
+// formed as (X.re, Y.re) and (X.im, Y.im) so that both squares and both sums are one v_pk_mul_f32 + one v_pk_fma_f32.
+__device__ __forceinline__ cf pair_powers(cf zk, cf zm, cf v) {
+  cf e, o, A, B;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(e) : "v"(zk), "v"(zm));   // zk + conj(zm)
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(o) : "v"(zk), "v"(zm));   // zk - conj(zm)
+  const cf t = cmul(o, v);
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(A) : "v"(e), "v"(t));  // (e.re + t.re, e.re - t.re)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(B) : "v"(e), "v"(t));  // (e.im + t.im, e.im - t.im)
+  return B * B + A * A;   // (|X[k]|^2, |X[NC-k]|^2)
+}
+
+// LDS tables of kernel A2, one row per FFT lane so that a lane fetches its constants with 16-byte reads: rows are an odd
+// number of 16-byte slots long, which puts the sixteen lanes of a frame on sixteen different slots (the four frames of a
+// wave read the same rows: broadcast).
+constexpr int kA2TabRow = 84;   // floats per lane (21 slots): 16 window pairs (w[2n], w[2n+1]), n = ls + 16 p; 16 stage-1
+                                // twiddles (p = 0 unused); 9 un-packing twiddles V[ls + 16 i], i < 8, and V[NC/2]
+constexpr int kA2TabFloats = 16 * kA2TabRow;
+
+// NW waves per workgroup (4 or 8), OCC waves per SIMD the build is register-budgeted for (4: 128, 5: 96, 6: 80 VGPRs).
+template <int PCM, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void dysf_stft_mel_wave_kernel(const KArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int NC = 256;
   using G = FftGeom<NC>;
   constexpr int L = G::L;
@@ -892,6 +919,7 @@ __global__ __launch_bounds__(256, 4) void dysf_stft_mel_wave_kernel(const KArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, ls = lane & 15;   // FFT roles: frame of the quad, lane of the frame
+  STAMP_INIT;
   const int mb = lane >> 2, mr = lane & 3;   // mel roles: block (four mels), A row / B column (mel of the block / frame)
   const int clip = blockIdx.y;
   const long long off = a.offsets[clip];
@@ -900,116 +928,193 @@ __global__ __launch_bounds__(256, 4) void dysf_stft_mel_wave_kernel(const KArgs 
   if (n64 <= 0 || T < 9 || T > a.t_max) return;  // rejected clips: kernel B writes their zero rows
   const int n = (int)n64;
   const int NQ = (T + 3) >> 2;
-  if (blockIdx.x * 4 * a.quads_per_wave >= NQ) return;  // whole workgroup beyond the clip
+  if (blockIdx.x * NW * a.quads_per_wave >= NQ) return;  // whole workgroup beyond the clip
 
   float* wregion = lds + a.lds_region + wave * kA2Region;
-  cf* win = (cf*)(lds + a.lds_tables);                       // [NC] (w[2n], w[2n+1]) / 2 (x 2^-15 for int16 PCM)
-  cf* ptw = (cf*)(lds + a.lds_tables + 2 * NC);              // [NC/2 + 1] un-packing twiddles
-  cf* t1s = (cf*)(lds + a.lds_tables + 2 * NC + 260);        // [16][L] stage-1 twiddles, point-major
-  float* melA = lds + a.lds_misc;                            // [rounds][steps/4][64][4]
+  float* tabT = lds + a.lds_tables;                          // [16 lanes][kA2TabRow]
+  float* melA = lds + a.lds_misc;                            // [rounds][steps/4][2 sets][64][4]
   {
-    const float* wsrc = (PCM == DYSF_PCM_I16) ? a.window_i16 : a.window;
-    for (int i = tid; i < 2 * NC; i += 256) ((float*)win)[i] = wsrc[i];
-    for (int i = tid; i < NC + 2; i += 256) ((float*)ptw)[i] = a.post_tw[i];
-    for (int i = tid; i < kPts * L; i += 256) t1s[i] = ((const cf*)a.stage_tw)[(i % L) * kPts + (i / L)];
-    const int nm = a.mel4_rounds * a.mel4_steps * 16;        // float4 count
-    for (int i = tid; i < nm; i += 256) ((float4*)melA)[i] = ((const float4*)a.mel4_pack)[i];
+    const float* wsrc = (PCM == DYSF_PCM_I16) ? a.window_i16 : a.window;   // window / 2 (x 2^-15 for int16 PCM)
+    for (int i = tid; i < 16 * 32; i += NT) {   // i = (lane l, float j): pair p = j / 2 of the points n = l + 16 p
+      const int l = i >> 5, j = i & 31;
+      tabT[l * kA2TabRow + j] = wsrc[2 * (l + L * (j >> 1)) + (j & 1)];
+      tabT[l * kA2TabRow + 32 + j] = a.stage_tw[(l * kPts + (j >> 1)) * 2 + (j & 1)];
+    }
+    for (int i = tid; i < 16 * 18; i += NT) {
+      const int l = i / 18, j = i % 18, k = (j >> 1) == 8 ? NC / 2 : l + L * (j >> 1);
+      tabT[l * kA2TabRow + 64 + j] = a.post_tw[2 * k + (j & 1)];
+    }
+    const int nm = a.mel4_rounds * a.mel4_steps * 32;        // float4 count
+    for (int i = tid; i < nm; i += NT) ((float4*)melA)[i] = ((const float4*)a.mel4_pack)[i];
     // the mel product reads a few words past a row's last bin and the exchange leaves one word per frame untouched
     for (int i = lane * 4; i < kA2Region; i += 256) *(float4*)(wregion + i) = float4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();  // the only barrier: tables are in place
+  STAMP(0);  // set-up
+  // The waves that share a SIMD come from different workgroups, start together and run the same program: without a
+  // stagger they stay in phase -- all in their VALU-heavy passes at once, then all in the exchange / MFMA / store
+  // passes with the VALU idle.  Each wave sleeps a quarter, half or three quarters of a quad first, keyed by the wave
+  // slot it occupies on its SIMD.
+  if (a.stagger_mode) {
+    int key;
+    if (a.stagger_mode == 1) key = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;   // HW_ID.wave_id
+    else if (a.stagger_mode == 2) key = blockIdx.y & 3;
+    else if (a.stagger_mode == 3) key = (blockIdx.y >> 3) & 3;
+    else if (a.stagger_mode == 4) key = (blockIdx.y >> 8) & 3;
+    else key = (blockIdx.y >> 5) & 3;
+    for (int i = 0; i < key * a.stagger_units; ++i) __builtin_amdgcn_s_sleep(8);   // 8 x 64 cycles per unit and key step
+  }
 
-  const int q_begin = (blockIdx.x * 4 + wave) * a.quads_per_wave;
+  const int q_begin = (blockIdx.x * NW + wave) * a.quads_per_wave;
   const int q_end = min(NQ, q_begin + a.quads_per_wave);
   if (q_begin >= q_end) return;
   const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
   float* xb = wregion + q * G::XSTRIDE;
   float* srow_own = wregion + q * kA2Kpad;
+  const float4* winr = (const float4*)(tabT + ls * kA2TabRow);   // one base register, constant offsets
+  const float4* twr = winr + 8;
+  const float4* ptwr = winr + 16;
   float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
   const int steps4 = a.mel4_steps >> 2;
-  int kbeg_r[2];  // first bin of this lane's block, per round (at most two rounds: n_mels <= 128)
-  kbeg_r[0] = a.mel4_kbeg[mb];
-  kbeg_r[1] = a.mel4_rounds > 1 ? a.mel4_kbeg[16 + mb] : 0;
   const unsigned long long lane0 = __ballot(ls == 0);
-  float lmax = 0.f;
+  unsigned lmax = 0u;  // bits of the largest mel power seen (non-negative floats order like their bits)
   float badacc = 0.f;  // float PCM: x * 0 summed over every sample is NaN iff one of them is not finite
 
+  // int16 PCM: the next quad's samples are requested a quad ahead (16 registers); float PCM would need 32, which does not
+  // fit beside the FFT, and neither do the 16 at six waves per SIMD: those loads are issued at the top of the quad that
+  // uses them (the other waves of the SIMD cover their latency)
+  constexpr bool AHEAD = PCM == DYSF_PCM_I16 && OCC <= 5;
   QuadPcm<PCM> st;
-  quad_prefetch<PCM>(st, pbase, n, T, a.hop, 4 * q_begin, q, ls);
+  if (AHEAD) quad_prefetch<PCM>(st, pbase, n, T, a.hop, 4 * q_begin, q, ls);
   for (int qi = q_begin; qi < q_end; ++qi) {
     const int f0 = 4 * qi;
+    if (!AHEAD) quad_prefetch<PCM>(st, pbase, n, T, a.hop, f0, q, ls);
     cf z[kPts];
 #pragma unroll
     for (int p = 0; p < kPts; ++p) {
-      cf x;
       if (PCM == DYSF_PCM_I16) {
-        x[0] = (float)(short)(st.v[p] & 0xffff); x[1] = (float)(st.v[p] >> 16);
+        z[p][0] = (float)(short)(st.v[p] & 0xffff); z[p][1] = (float)(st.v[p] >> 16);
       } else {
-        x[0] = __int_as_float(st.v[2 * p]); x[1] = __int_as_float(st.v[2 * p + 1]);
-        badacc = fmaf(x[0], 0.f, badacc); badacc = fmaf(x[1], 0.f, badacc);
+        z[p][0] = __int_as_float(st.v[2 * p]); z[p][1] = __int_as_float(st.v[2 * p + 1]);
+        badacc = fmaf(z[p][0], 0.f, badacc); badacc = fmaf(z[p][1], 0.f, badacc);
       }
-      z[p] = x * win[ls + L * p];
     }
-    if (qi + 1 < q_end) quad_prefetch<PCM>(st, pbase, n, T, a.hop, f0 + 4, q, ls);  // in flight during this quad's FFT
-    fft_stage<NC, 0>(z, (const cf*)nullptr);
-    fft_exchange<NC, 0>(z, xb, ls);
-    {
-      cf t1[kPts];
+    // the staging registers are free: the next quad's samples are in flight during this quad's FFT (the fence keeps the
+    // loads behind the conversions, so they land in the same registers and no copies are needed at the loop end)
+    __builtin_amdgcn_sched_barrier(0);
+    if (AHEAD && qi + 1 < q_end) quad_prefetch<PCM>(st, pbase, n, T, a.hop, f0 + 4, q, ls);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int p = 0; p < kPts; ++p) t1[p] = t1s[p * L + ls];
-      fft_stage<NC, 1>(z, t1);
+    for (int j = 0; j < 8; ++j) {
+      const float4 w = winr[j];
+      z[2 * j] *= mk(w.x, w.y);
+      z[2 * j + 1] *= mk(w.z, w.w);
     }
+    fft_stage<NC, 0>(z, (const cf*)nullptr);
+    STAMP(1);  // conversion, prefetch issue, window, first radix-16 pass
+    // transpose through the frame's exchange buffer, real parts then imaginary parts (volatile: single ds_read_b32s land
+    // in the registers of the pairs they belong to; merged ds_read2_b32 results need a v_mov each)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) xb[pad_idx(fft_out_index<NC, 0>(ls, p))] = z[p][h];
+      wave_lds_sync();
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) z[p][h] = ((const lds_vfloat*)xb)[pad_idx(fft_in_index<NC>(ls, p))];
+      wave_lds_sync();
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (table reads hoisted across the phases cost more registers than they hide latency)
+    STAMP(2);  // exchange
+    // stage-1 twiddles in two batches of four 16-byte reads (a batch is dead once its eight products are formed)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int j = 4 * half; j < 4 * half + 4; ++j) {
+        const float4 w = twr[j];
+        if (j > 0) z[2 * j] = cmul(z[2 * j], mk(w.x, w.y));
+        z[2 * j + 1] = cmul(z[2 * j + 1], mk(w.z, w.w));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fft_butterflies<NC, 1>(z);
+    STAMP(3);  // twiddles + second radix-16 pass
     // un-packing: register p of lane ls holds Z[ls + 16 p]; Z[NC - k] sits in register 15 - i of lane 16 - ls (lane 0
     // pairs with itself, one register on): row_mirror + row_ror:1, as in kernel A
-    cf zm[9];
+    __builtin_amdgcn_sched_barrier(0);
+    cf vtw[9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 w = ptwr[j];
+      vtw[2 * j] = mk(w.x, w.y); vtw[2 * j + 1] = mk(w.z, w.w);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      cf zm;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float offer;
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
         const int m = __builtin_amdgcn_mov_dpp(__float_as_int(offer), 0x140, 0xf, 0xf, true);
-        zm[i][h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
+        zm[h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
       }
+      const cf pw = pair_powers(z[i], zm, vtw[i]);
+      const int k = ls + L * i;
+      srow_own[k] = pw[0];
+      srow_own[NC - k] = pw[1];
     }
-    zm[8] = z[8];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int k = (i == 8) ? NC / 2 : ls + L * i;
-      float pk, pm;
-      rfft_pair_power(z[i], zm[i], ptw[k], &pk, &pm);
-      if (i < 8 || ls == 0) {
-        srow_own[k] = pk;
-        srow_own[NC - k] = pm;
-      }
+    {  // bin NC/2 pairs with itself: X = 2 conj(Z) (V = -1), |X|^2 = 4 |Z|^2; lane 0 holds it
+      const cf d = z[8] + z[8], m = d * d;
+      if (ls == 0) srow_own[NC / 2] = m[0] + m[1];
     }
     wave_lds_sync();
-    // mel product: D_b[4 mels x 4 frames] += A_b[4 x 1] * B_b[1 x 4] per K-step, the sixteen blocks in one instruction
+    STAMP(4);  // un-packing, powers, row stores
+    // mel product: D_b[4 mels x 4 frames] += A_b[4 x 1] * B_b[1 x 4] per K-step, the sixteen blocks in one instruction.
+    // Two accumulator sets follow the host's schedule (build_mel4): the long bands of the high mels are cut into pieces
+    // that run in otherwise idle blocks; the two sets' instructions alternate, so no MFMA waits for its predecessor.
     for (int rd = 0; rd < a.mel4_rounds; ++rd) {
-      const float4* Ap = (const float4*)melA + (size_t)rd * steps4 * 64 + lane;
-      const float4* Bp = (const float4*)(wregion + mr * kA2Kpad + (rd ? kbeg_r[1] : kbeg_r[0]));
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+      const int* meta = a.mel4_kbeg + rd * 48;
+      const float4* Ap = (const float4*)melA + (size_t)rd * steps4 * 128 + lane;
+      const float4* B0 = (const float4*)(wregion + mr * kA2Kpad + meta[mb]);
+      const float4* B1 = (const float4*)(wregion + mr * kA2Kpad + meta[16 + mb]);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       for (int s = 0; s < steps4; ++s) {
-        const float4 av = Ap[s * 64], bv = Bp[s];
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc, 0, 0, 0);
+        const float4 a0 = Ap[(2 * s) * 64], a1 = Ap[(2 * s + 1) * 64], b0 = B0[s], b1 = B1[s];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, acc1, 0, 0, 0);
       }
-      // lane (block mb, column mr) holds mels 64 rd + 4 mb + {0..3} of frame f0 + mr
-      const int t = f0 + mr, m0 = 64 * rd + 4 * mb;
-      if (t < T && m0 < a.lm_stride) {
+      STAMP(5);  // mel MFMA loop
+      // pieces -> groups: a DPP row is four blocks (banks of four lanes).  row_shl:n reads lane i + n.
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = acc0[i], y = acc1[i];
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0x5, false));  // blocks 0, 2 += blocks 1, 3
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xf, 0x1, false));  // block 0 += block 2
+        y += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x104, 0xf, 0x4, false));  // block 2 += block 3
+        // block 3 of set 1 takes the row's finished set-0 group (row_shr:12 reads lane i - 12)
+        acc1[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(y), __float_as_int(x), 0x11c, 0xf, 0x8, false));
+      }
+      // lane (block mb, column mr) now holds the four mels from meta[32 + mb] on of frame f0 + mr
+      const int t = f0 + mr, m0 = meta[32 + mb];
+      if (t < T && m0 >= 0) {
         float4 v;
-        v.x = power_to_db(acc[0], a); v.y = power_to_db(acc[1], a); v.z = power_to_db(acc[2], a); v.w = power_to_db(acc[3], a);
+        v.x = power_to_db(acc1[0], a); v.y = power_to_db(acc1[1], a); v.z = power_to_db(acc1[2], a); v.w = power_to_db(acc1[3], a);
         *(float4*)(lm + (size_t)t * a.lm_stride + m0) = v;
-        lmax = fmaxf(fmaxf(lmax, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+        lmax = max(max(lmax, max(__float_as_uint(acc1[0]), __float_as_uint(acc1[1]))),
+                   max(__float_as_uint(acc1[2]), __float_as_uint(acc1[3])));
       }
     }
     wave_lds_sync();
+    STAMP(6);  // dB + store
   }
-  lmax = wave_max(lmax);
-  if (lane == 0) atomicMax(a.ws_clipmax + clip, __float_as_uint(fmaxf(lmax, 0.f)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, (unsigned)__shfl_xor((int)lmax, o));
+  if (lane == 0) atomicMax(a.ws_clipmax + clip, lmax);
   if (PCM == DYSF_PCM_F32 && !(badacc == 0.f)) a.ws_flags[clip] = 1;
 }
 
@@ -1964,9 +2069,21 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
-  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_I16>, grid, 256, lds_bytes, s, a);
-  return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_F32>, grid, 256, lds_bytes, s, a);
+template <int NW, int OCC>
+static hipError_t launch_a2(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_I16, NW, OCC>, grid, 64 * NW, lds_bytes, s, a);
+  // float PCM stages twice the registers per quad: only the 128-register build holds them without scratch
+  return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_F32, NW, 4>, grid, 64 * NW, lds_bytes, s, a);
+}
+hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, int waves_per_wg, int waves_per_simd, dim3 grid, size_t lds_bytes,
+                                hipStream_t s) {
+  if (waves_per_wg == 8) {
+    if (waves_per_simd >= 6) return launch_a2<8, 6>(a, pcm_type, grid, lds_bytes, s);
+    return launch_a2<8, 4>(a, pcm_type, grid, lds_bytes, s);
+  }
+  if (waves_per_simd >= 6) return launch_a2<4, 6>(a, pcm_type, grid, lds_bytes, s);
+  if (waves_per_simd == 5) return launch_a2<4, 5>(a, pcm_type, grid, lds_bytes, s);
+  return launch_a2<4, 4>(a, pcm_type, grid, lds_bytes, s);
 }
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s) {
   // up to 64 mels: mean-free float32 MFMA.  The eight-group form of it spills its statistics accumulators, so the

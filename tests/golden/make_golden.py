@@ -21,6 +21,11 @@ Outputs (all under tests/golden/):
   forest_after.npz         the RandomForest(200) of pipeline1.py:496 as flat node arrays + expected outputs
   clean_pin.json           peak / header statistics of all clear_audio/*.wav: what the last two steps of
                            clean_audio_and_cache (librosa.util.normalize + sf.write PCM_16, p1:140-141) leave behind
+  tuning_888.json          (--tuning-888) the oracle's estimate_tuning index of every one of the 888 reference clips
+  deployed_models.npz      (--deployed) the models main1.py:859-868 defines -- RandomForest(600), MLP(256,128,64),
+                           SVC(C=10), soft VotingClassifier -- validated by re-running its 5-fold CV (m1:874-893) against
+                           output_results/FINAL_PERFORMANCE_TABLE.csv, then fitted on all 905 scaled rows as m1:896 does
+                           for the forest it serves (m1:984-989); scikit-learn's predict / predict_proba on the 905 rows
 """
 import csv
 import glob
@@ -314,7 +319,121 @@ def clean_pin():
     print("clean_pin:", {k: (v if not isinstance(v, list) else len(v)) for k, v in rec.items()})
 
 
+def tuning_888():
+    """The oracle's tuning index (librosa.estimate_tuning inside chroma_stft, pipeline1.py:227) of all 888 reference
+    clips, by stem: the histogram arg-max is a tie or near-tie in most clips, so the GPU test compares indices exactly."""
+    from multiprocessing import Pool
+    stems = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(REF, "clear_audio", "*.wav"))
+                   if os.path.exists(os.path.join(REF, "cache_features", os.path.basename(f)[:-4] + "_clean_feats.npy")))
+    with Pool(min(8, os.cpu_count() or 1)) as pool:
+        idx = pool.map(_tuning_of, stems, chunksize=8)
+    with open(os.path.join(HERE, "tuning_888.json"), "w") as fh:
+        json.dump({"what": "oracle/dysf_oracle.py estimate_tuning index (0..99) of the reference clips clear_audio/<stem>.wav, "
+                           "by stem; tests/golden/make_golden.py --tuning-888", "tuning_index": dict(zip(stems, idx))}, fh, indent=0)
+    print("tuning_888:", len(stems), "clips")
+
+
+def _tuning_of(stem):
+    pcm, sr = O.read_wav_pcm16(os.path.join(REF, "clear_audio", stem + ".wav"))
+    return int(O.estimate_tuning(O.stft_power(O.pcm16_to_float(pcm), O.REFERENCE_149), O.REFERENCE_149)[1]["index"])
+
+
+def _flat_forest(rf):
+    feat, thr, left, right, value, root = [], [], [], [], [], []
+    for est in rf.estimators_:
+        t = est.tree_
+        root.append(len(feat))
+        base = len(feat)
+        feat += t.feature.tolist()
+        thr += t.threshold.tolist()
+        left += [c + base if c >= 0 else -1 for c in t.children_left]
+        right += [c + base if c >= 0 else -1 for c in t.children_right]
+        value += t.value[:, 0, :].tolist()
+    return {"feature": np.array(feat, np.int32), "threshold": np.array(thr, np.float64), "left": np.array(left, np.int32),
+            "right": np.array(right, np.int32), "value": np.array(value, np.float64), "root": np.array(root, np.int32)}
+
+
+def deployed_fixture():
+    """The classifiers main1.py defines (m1:859-868), cross-validated exactly as m1:856, 874-893 does, compared with the
+    reference's own FINAL_PERFORMANCE_TABLE.csv, then fitted on ALL 905 scaled rows -- what m1:896-897 does for the forest
+    the sidebar serves (m1:984-989; the stored model_rf.pkl is a missing blob).  The soft-voting ensemble of m1:867 clones
+    and re-fits the three base models, so its probabilities are the mean of theirs (checked below)."""
+    from sklearn.ensemble import RandomForestClassifier, VotingClassifier
+    from sklearn.metrics import accuracy_score, precision_recall_fscore_support
+    from sklearn.model_selection import StratifiedKFold
+    from sklearn.neural_network import MLPClassifier
+    from sklearn.preprocessing import LabelEncoder, StandardScaler
+    from sklearn.svm import SVC
+
+    files = list_audio_files(os.path.join(REF, "segrigated_samples"))
+    labels = [os.path.basename(os.path.dirname(f)) for f in files]
+    X_after = np.vstack([np.load(os.path.join(REF, "cache_features",
+                                              os.path.basename(f).rsplit(".", 1)[0] + "_clean_feats.npy")) for f in files])
+    le = LabelEncoder()
+    y = le.fit_transform(labels)
+    scaler = StandardScaler()
+    Xs = scaler.fit_transform(X_after)
+    skf = StratifiedKFold(n_splits=5, shuffle=True, random_state=42)
+
+    def make():
+        base = {
+            "RandomForest": RandomForestClassifier(n_estimators=600, max_depth=None, min_samples_split=2, min_samples_leaf=1,
+                                                   random_state=42, n_jobs=-1),
+            "MLP": MLPClassifier(hidden_layer_sizes=(256, 128, 64), max_iter=1200, alpha=1e-4, learning_rate="adaptive",
+                                 random_state=42),
+            "SVM": SVC(probability=True, C=10, gamma="scale", random_state=42),
+        }
+        ens = VotingClassifier(estimators=[(k, v) for k, v in base.items()], voting="soft")
+        return {**base, "Ensemble": ens}
+
+    ref_table = {}
+    with open(os.path.join(REF, "output_results", "FINAL_PERFORMANCE_TABLE.csv")) as f:
+        for r in csv.DictReader(f):
+            ref_table[r["Model"]] = [float(r["Accuracy (%)"]), float(r["Precision (%)"]), float(r["Recall (%)"]), float(r["F1-Score (%)"])]
+    models = make()
+    cv = {}
+    for name, model in models.items():
+        accs, precs, recs, f1s = [], [], [], []
+        for tr, te in skf.split(Xs, y):
+            model.fit(Xs[tr], y[tr])
+            pred = model.predict(Xs[te])
+            pr, rc, f1, _ = precision_recall_fscore_support(y[te], pred, average="macro", zero_division=0)
+            accs.append(accuracy_score(y[te], pred)); precs.append(pr); recs.append(rc); f1s.append(f1)
+        cv[name] = [float(np.mean(v) * 100) for v in (accs, precs, recs, f1s)]
+        print(name, "cv", cv[name], "reference", ref_table.get(name))
+    evidence = {"cv_5fold": cv, "reference_FINAL_PERFORMANCE_TABLE": ref_table,
+                "max_abs_diff_vs_reference": {k: float(np.max(np.abs(np.array(cv[k]) - np.array(ref_table[k])))) for k in cv},
+                "sklearn": __import__("sklearn").__version__}
+    # the deployed fits: all 905 rows (m1:896)
+    rf, mlp, svc, ens = models["RandomForest"], models["MLP"], models["SVM"], models["Ensemble"]
+    rf.fit(Xs, y); mlp.fit(Xs, y); svc.fit(Xs, y); ens.fit(Xs, y)
+    mean_proba = (rf.predict_proba(Xs) + mlp.predict_proba(Xs) + svc.predict_proba(Xs)) / 3.0
+    evidence["ensemble_is_mean_of_the_three"] = float(np.abs(ens.predict_proba(Xs) - mean_proba).max())
+    print(json.dumps(evidence, indent=1))
+    svc.decision_function_shape = "ovo"
+    out = {"X": X_after.astype(np.float32), "y": y.astype(np.int64), "classes": np.array(le.classes_),
+           "mean": scaler.mean_, "scale": scaler.scale_, "evidence": json.dumps(evidence)}
+    out.update({"rf_" + k: v for k, v in _flat_forest(rf).items()})
+    out.update({"rf_pred": rf.predict(Xs).astype(np.int64), "rf_proba": rf.predict_proba(Xs)})
+    for i, (W, b) in enumerate(zip(mlp.coefs_, mlp.intercepts_)):
+        out["mlp_W%d" % (i + 1)] = W; out["mlp_b%d" % (i + 1)] = b
+    out.update({"mlp_pred": mlp.predict(Xs).astype(np.int64), "mlp_proba": mlp.predict_proba(Xs)})
+    out.update({"svc_support_vectors": svc.support_vectors_.astype(np.float64), "svc_dual_coef": svc.dual_coef_.astype(np.float64),
+                "svc_intercept": svc.intercept_.astype(np.float64), "svc_prob_a": svc.probA_.astype(np.float64),
+                "svc_prob_b": svc.probB_.astype(np.float64), "svc_n_support": svc.n_support_.astype(np.int32),
+                "svc_gamma": np.float64(svc._gamma), "svc_pred": svc.predict(Xs).astype(np.int64),
+                "svc_proba": svc.predict_proba(Xs), "svc_decision": svc.decision_function(Xs)})
+    out.update({"ens_pred": ens.predict(Xs).astype(np.int64), "ens_proba": ens.predict_proba(Xs)})
+    np.savez_compressed(os.path.join(HERE, "deployed_models.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--tuning-888" in sys.argv:
+        tuning_888()
+        sys.exit(0)
+    if "--deployed" in sys.argv:
+        deployed_fixture()
+        sys.exit(0)
     if "--clean-pin-only" in sys.argv:
         clean_pin()
         sys.exit(0)

@@ -1123,3 +1123,143 @@ def test_cleaning_stage_other_rates_and_lengths(sr, n):
     d = np.abs(res["pcm16"][0].astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and int((d != 0).sum()) <= 2, (int(d.max()), int((d != 0).sum()))
     cl.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# All 888 reference pairs and the models main1.py deploys (round 3)
+
+def test_reference_888_pairs_all_features_tuning_and_metrics(golden_dir):
+    """EVERY known-answer pair the reference holds: clear_audio/<stem>.wav -> cache_features/<stem>_clean_feats.npy (888
+    pairs; the audio travels to the GPU box in the git-ignored tests/golden/_all888/, so the test skips where it is
+    absent).  One batched launch.  Asserted: all 149 values of every clip within the north-star 1e-4; the tuning index of
+    chroma_stft equal to the oracle's (tests/golden/tuning_888.json) on every clip; the three per-file metrics of
+    pipeline1.py:151-186 against the reference's own per_file_analysis.csv values (tolerances of
+    test_audio_metrics_match_reference_csv_and_oracle)."""
+    d = os.path.join(golden_dir, "_all888")
+    if not os.path.exists(os.path.join(d, "index.json")):
+        pytest.skip("tests/golden/_all888 (the reference's 888 WAV / vector pairs) is not on this machine")
+    idx = json.load(open(os.path.join(d, "index.json")))
+    assert len(idx) == 888
+    want_tuning = json.load(open(os.path.join(golden_dir, "tuning_888.json")))["tuning_index"]
+    clips, golds = [], []
+    for e in idx:
+        pcm, sr = O.read_wav_pcm16(os.path.join(d, e["id"] + ".wav"))
+        assert sr == 16000
+        clips.append(pcm); golds.append(np.load(os.path.join(d, e["id"] + ".npy")))
+    ex = rsd_amd.get_extractor(P149, 0)
+    res = ex.extract_batch(clips, tuning=True)
+    assert (res["status"] == 0).all()
+    G = np.stack(golds).astype(np.float64)
+    F = np.hstack([res["pooled"], np.zeros((len(clips), 5), np.float32)]).astype(np.float64)
+    D = np.abs(F - G)
+    worst = int(D.max(axis=1).argmax())
+    print("888 pairs: max |gpu - reference| %.3e (clip %s, feature %d), p99 of per-clip maxima %.3e, chroma block max %.3e"
+          % (D.max(), idx[worst]["stem"], int(D[worst].argmax()), np.percentile(D.max(axis=1), 99), D[:, 120:144].max()))
+    assert D.max() <= 1e-4, (idx[worst]["stem"], float(D.max()), int(D[worst].argmax()))
+    assert int((D.max(axis=1) <= 1e-4).sum()) == 888
+    mism = [(e["stem"], int(t), want_tuning[e["stem"]]) for e, t in zip(idx, res["tuning"]) if int(t) != want_tuning[e["stem"]]]
+    assert not mism, mism[:5]
+    have = [i for i, e in enumerate(idx) if e.get("metrics_after")]
+    assert len(have) == 888
+    gm = rsd_amd.audio_metrics_batch([clips[i] for i in have], 16000)
+    wm = np.array([idx[i]["metrics_after"] for i in have])
+    assert np.abs(gm[:, 0] - wm[:, 0]).max() <= 2e-4
+    assert (np.abs(gm[:, 1] - wm[:, 1]) / wm[:, 1]).max() <= 5e-4
+    assert (np.abs(gm[:, 2] - wm[:, 2]) / wm[:, 2]).max() <= 2e-5
+
+
+def _deployed(golden_dir):
+    return os.path.join(golden_dir, "deployed_models.npz")
+
+
+def test_deployed_forest_600_trees_all_rows(golden_dir):
+    """The forest main1.py serves (m1:860-862 fitted on all 905 scaled rows, m1:896-897): RandomForest(600) as flat node
+    arrays (313 k nodes), walked by dysf_forest_predict_dev.  scikit-learn's predict exact, predict_proba to 1e-12."""
+    from rsd_amd.classifier import RandomForestHead
+    z = np.load(_deployed(golden_dir))
+    assert len(z["rf_root"]) == 600
+    head = RandomForestHead.from_npz(_deployed(golden_dir), prefix="rf_")
+    x = torch.from_numpy(z["X"]).cuda()
+    assert np.array_equal(head.predict(x).cpu().numpy(), z["rf_pred"])
+    assert np.abs(head.predict_proba(x).cpu().numpy() - z["rf_proba"]).max() <= 1e-12
+    head.close()
+
+
+def test_deployed_mlp_three_hidden_layers(golden_dir):
+    """MLPClassifier(256, 128, 64) of m1:863-864 through the one-kernel MFMA head and the eager head: scikit-learn's arg-max
+    on every row whose top-two probability margin exceeds float32 noise (1e-3), probabilities within 1e-4."""
+    from rsd_amd.classifier import FusedMLPHead, MLPHead
+    z = np.load(_deployed(golden_dir))
+    fused = FusedMLPHead.from_npz(_deployed(golden_dir), prefix="mlp_")
+    eager = MLPHead.from_npz(_deployed(golden_dir), prefix="mlp_").cuda()
+    assert len(eager.weights) == 4
+    x = torch.from_numpy(z["X"]).cuda()
+    srt = np.sort(z["mlp_proba"], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-3
+    for head in (fused, eager):
+        assert np.abs(head.predict_proba(x).cpu().numpy() - z["mlp_proba"]).max() <= 1e-4
+        assert np.array_equal(head.predict(x).cpu().numpy()[clear], z["mlp_pred"][clear])
+    assert clear.mean() > 0.99
+    fused.close()
+
+
+def test_deployed_svc_c10(golden_dir):
+    """SVC(C=10, gamma='scale', probability=True) of m1:865 fitted on all rows: decision values and coupled Platt
+    probabilities to 1e-9, one-vs-one votes exact."""
+    from rsd_amd.classifier import SVCHead
+    z = np.load(_deployed(golden_dir))
+    head = SVCHead.from_npz(_deployed(golden_dir), prefix="svc_")
+    x = torch.from_numpy(z["X"]).cuda()
+    assert np.abs(head.decision_function(x).cpu().numpy() - z["svc_decision"]).max() <= 1e-9
+    assert np.array_equal(head.predict(x).cpu().numpy(), z["svc_pred"])
+    assert np.abs(head.predict_proba(x).cpu().numpy() - z["svc_proba"]).max() <= 1e-9
+    head.close()
+
+
+def test_deployed_soft_voting_ensemble(golden_dir):
+    """VotingClassifier(voting='soft') of m1:867-868 over the three deployed models against scikit-learn's own ensemble
+    outputs (its members are clones re-fitted on the same rows: the fixture records that their mean equals it)."""
+    from rsd_amd.classifier import FusedMLPHead, RandomForestHead, SVCHead, SoftVotingHead
+    z = np.load(_deployed(golden_dir))
+    assert json.loads(str(z["evidence"]))["ensemble_is_mean_of_the_three"] < 1e-12
+    heads = [RandomForestHead.from_npz(_deployed(golden_dir), prefix="rf_"),
+             FusedMLPHead.from_npz(_deployed(golden_dir), prefix="mlp_"),
+             SVCHead.from_npz(_deployed(golden_dir), prefix="svc_")]
+    vote = SoftVotingHead(heads)
+    x = torch.from_numpy(z["X"]).cuda()
+    got = vote.predict_proba(x).cpu().numpy()
+    assert np.abs(got - z["ens_proba"]).max() <= 1e-4
+    srt = np.sort(z["ens_proba"], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-3
+    assert np.array_equal(vote.predict(x).cpu().numpy()[clear], z["ens_pred"][clear]) and clear.mean() > 0.97
+
+
+def test_deployed_predictor_with_the_served_forest(golden_dir, tmp_path):
+    """main1.py:970-990 end to end with the model it names: reference WAV (already cleaned: memoised in clear_audio/) ->
+    features -> guard -> scaler + RandomForest(600, all rows) -> label string, against scikit-learn's label and
+    probabilities for the reference's cached vector of the same clip."""
+    from rsd_amd.classifier import RandomForestHead
+    z = np.load(_deployed(golden_dir))
+    classes = [str(c) for c in z["classes"]]
+    rf = RandomForestHead.from_npz(_deployed(golden_dir), classes=classes, prefix="rf_")
+    clear = tmp_path / "clear_audio"
+    clear.mkdir()
+    dp = rsd_amd.DeployedPredictor(rf, classes, clear_dir=str(clear))
+    idx = json.load(open(os.path.join(golden_dir, "ref_pairs", "index.json")))
+    n = 0
+    for (cid, pcm, sr, gold), e in zip(_pairs(golden_dir), idx):
+        rows = np.nonzero((z["X"] == gold[None, :]).all(axis=1))[0]
+        if len(rows) == 0:
+            continue
+        up = tmp_path / f"{e['reference_stem']}.wav"
+        rsd_amd.write_wav_pcm16(str(up), pcm, 16000)
+        rsd_amd.write_wav_pcm16(str(clear / up.name), pcm, 16000)
+        label, prob = dp.predict_file(str(up))
+        # the GPU features differ from the cached vector by <= 1e-4: a split threshold can fall in between on a few trees
+        assert max(abs(prob[k] - z["rf_proba"][rows[0]][i]) for i, k in enumerate(classes)) <= 0.0051, cid
+        srt = np.sort(z["rf_proba"][rows[0]])
+        if srt[-1] - srt[-2] > 0.011:
+            assert label == classes[int(z["rf_pred"][rows[0]])], (cid, label)
+        n += 1
+    assert n >= 12
+    rf.close()
