@@ -271,8 +271,9 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
  *   d_status        [n_clips] DYSF_OK, DYSF_EMPTY, DYSF_TOO_LONG (the clip has more samples than max_samples: left
  *                   untouched) or DYSF_NONFINITE (the gate produced a non-finite sample, e.g. an all-zero clip:
  *                   librosa.util.normalize raises there and the reference writes no file)
- * max_samples beyond noisereduce's chunk_size (600 000 samples) is rejected.  A handle owns its workspaces: use one
- * handle per stream (work queued on one stream is ordered).
+ * Clips beyond noisereduce's chunk_size (600 000 samples) are gated as noisereduce gates them: in full 600 000-sample
+ * spans, each padded with its 30 000 neighbouring samples and filtered on its own (main1.py's 126.5 s sidebar uploads
+ * took this path).  A handle owns its workspaces: use one handle per stream (work queued on one stream is ordered).
  */
 typedef struct DysfCleaner DysfCleaner;
 const char* dysf_clean_last_error(void);

@@ -33,6 +33,7 @@ import scipy.signal
 # noisereduce.spectralgate.base.SpectralGate (defaults of nr.reduce_noise)
 N_FFT = 1024
 PADDING = 30000
+CHUNK_SIZE = 600000
 TIME_CONSTANT_S = 2.0
 FREQ_MASK_SMOOTH_HZ = 500
 TIME_MASK_SMOOTH_MS = 50
@@ -86,17 +87,32 @@ def spectral_gate_nonstationary(chunk: np.ndarray, sr: int, prop_decrease: float
 
 
 def reduce_noise(y: np.ndarray, sr: int, prop_decrease: float = 1.0) -> np.ndarray:
-    """nr.reduce_noise(y=y, sr=sr[, prop_decrease=...]) for a mono clip shorter than chunk_size (600 000 samples):
-    SpectralGate.get_traces -> filter_chunk(0, n): zero padding of 30 000 samples each side in a float64 chunk
-    (``_read_chunk`` builds it with np.zeros), gate, crop, cast back to the input dtype."""
+    """nr.reduce_noise(y=y, sr=sr[, prop_decrease=...]) for a mono clip, as SpectralGate.get_traces runs it with the
+    defaults chunk_size=600000, padding=30000:
+      * n <= chunk_size: filter_chunk(0, n) -- the clip between 30 000 zeros each side in a float64 chunk (``_read_chunk``
+        builds it with np.zeros), gate, crop;
+      * longer clips (the reference's sidebar uploads of 126.5 s went this way, main1.py:598-611): chunk k is the FULL span
+        [k * chunk_size, (k + 1) * chunk_size) -- also the last one, read past the end as zeros -- padded with the 30 000
+        REAL neighbouring samples either side (zeros outside the clip), filtered on its own, cropped to the span, and
+        the spans are concatenated up to n.
+    The result is cast back to the input dtype."""
     y = np.asarray(y)
     n = y.shape[-1]
-    if n > 600000:
-        raise NotImplementedError("chunked processing of clips beyond noisereduce's chunk_size is not restated")
-    chunk = np.zeros(n + 2 * PADDING)
-    chunk[PADDING:PADDING + n] = y
-    filtered = spectral_gate_nonstationary(chunk, sr, prop_decrease)
-    return filtered[PADDING:PADDING + n].astype(y.dtype)
+
+    def filter_chunk(start, end):   # SpectralGate.filter_chunk / _read_chunk
+        i1, i2 = start - PADDING, end + PADDING
+        chunk = np.zeros(i2 - i1)
+        i1b, i2b = max(i1, 0), min(i2, n)
+        chunk[i1b - i1:i2b - i1] = y[i1b:i2b]
+        return spectral_gate_nonstationary(chunk, sr, prop_decrease)[start - i1:end - i1]
+
+    if n <= CHUNK_SIZE:
+        return filter_chunk(0, n).astype(y.dtype)
+    out = np.zeros(n, dtype=y.dtype)
+    for k in range((n - 1) // CHUNK_SIZE + 1):
+        start0, end0 = k * CHUNK_SIZE, min((k + 1) * CHUNK_SIZE, n)
+        out[start0:end0] = filter_chunk(k * CHUNK_SIZE, (k + 1) * CHUNK_SIZE)[:end0 - start0]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

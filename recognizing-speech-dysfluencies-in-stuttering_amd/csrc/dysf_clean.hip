@@ -4,7 +4,10 @@
 //     sf.write(out_path, y_clean, sr)              pipeline1.py:141  (PCM_16)
 // noisereduce's default gate (stationary=False, SpectralGateNonStationary) is glue over SciPy; every step below follows
 // the SciPy call it makes, in float64 like the float64 chunk noisereduce builds (oracle/dysf_clean_oracle.py):
-//   pad     30 000 zeros each side of the clip (SpectralGate._read_chunk), then scipy.signal.stft's own 512 zeros
+//   chunk   clips up to chunk_size (600 000 samples) are one chunk: the clip between 30 000 zeros (SpectralGate._read_chunk);
+//           longer clips (the reference's 126.5 s sidebar uploads, main1.py:598-611) are cut into full 600 000-sample spans,
+//           each padded with its 30 000 real neighbouring samples either side (zeros outside the clip) and gated on its own
+//           (SpectralGate.get_traces / filter_chunk); then scipy.signal.stft's own 512 zeros
 //   stft    hann(1024, periodic), hop 256, rfft / sum(window)                               clean_stft_kernel
 //   smooth  |X| through filtfilt([b], [1, b - 1], padtype=None) along time: a one-pole low-pass run forward and
 //           backward from steady-state initial conditions; mask = sigmoid((|X| - s) / s, -2, 10)   clean_gate_kernel
@@ -40,7 +43,9 @@ constexpr int kMaxTaps = 129;     // per axis of the mask blur
 struct CleanDev {
   const void* pcm; const long long* offsets; int pcm_type;
   int clip0;                 // first clip of this sub-batch
-  int padding;               // zeros either side (30 000)
+  int padding;               // samples either side of a chunk (30 000): zeros outside the clip
+  long long chunk;           // noisereduce's chunk_size (600 000)
+  int nch;                   // chunks of the longest clip: the workspaces hold [clip][nch] jobs
   int t_max;                 // frame stride of the workspaces
   long long max_samples;     // the caller's bound on a clip's length: longer clips are rejected (DYSF_TOO_LONG), not processed
   double b;                  // one-pole coefficient of the time smoothing
@@ -66,6 +71,19 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 }
 
 __device__ __forceinline__ int frames_of(long long n, int padding) { return (int)((n + 2LL * padding) / kHop) + 1; }
+
+// One gating job = one chunk of one clip: the span [c0, c0 + L) of the clip inside `padding` samples either side.
+struct Job { long long off, n, c0, L; int T; bool ok; };
+__device__ __forceinline__ Job job_of(const CleanDev& c, int lc, int k) {
+  Job j;
+  const int clip = c.clip0 + lc;
+  j.off = c.offsets[clip]; j.n = c.offsets[clip + 1] - j.off;
+  j.ok = j.n > 0 && j.n <= c.max_samples;
+  if (j.n <= c.chunk) { j.c0 = 0; j.L = j.n; j.ok = j.ok && k == 0; }
+  else { j.c0 = (long long)k * c.chunk; j.L = c.chunk; j.ok = j.ok && j.c0 < j.n; }   // every chunk spans chunk_size, the last one too
+  j.T = j.ok ? frames_of(j.L, c.padding) : 0;
+  return j;
+}
 
 // 1024-point forward FFT of buf[0] (Stockham autosort, five radix-4 passes, thread j owns butterfly j of a pass);
 // returns the buffer index that holds the result.  The index maps are those of dysf_hfratio.hip's global passes.
@@ -98,19 +116,23 @@ __device__ __forceinline__ int fft1024(double2 (*buf)[kN], const double2* tw, in
 
 __global__ __launch_bounds__(256) void clean_stft_kernel(CleanDev c) {
   __shared__ double2 buf[2][kN];
-  const int lc = blockIdx.y, clip = c.clip0 + lc, t = blockIdx.x, tid = threadIdx.x;
-  const long long off = c.offsets[clip], n = c.offsets[clip + 1] - off;
-  if (n <= 0 || n > c.max_samples || t >= frames_of(n, c.padding)) return;
+  const int job = blockIdx.y, lc = job / c.nch, t = blockIdx.x, tid = threadIdx.x;
+  const Job jb = job_of(c, lc, job % c.nch);
+  if (!jb.ok || t >= jb.T) return;
+  const long long off = jb.off, n = jb.n;
   for (int j = tid; j < kN; j += 256) {
-    const long long s = (long long)t * kHop + j - kN / 2 - c.padding;   // sample of the clip under tap j
+    // tap j sits at index u of the padded chunk; scipy.signal.stft's own boundary zeros lie outside [0, L + 2 padding) --
+    // where a chunk of a long clip has real neighbours, so the test is on u, not only on the clip's ends
+    const long long u = (long long)t * kHop + j - kN / 2;
+    const long long s = jb.c0 - c.padding + u;   // sample of the clip under tap j
     double v = 0.0;
-    if (s >= 0 && s < n)
+    if (u >= 0 && u < jb.L + 2LL * c.padding && s >= 0 && s < n)
       v = (c.pcm_type == DYSF_PCM_I16) ? (double)((const short*)c.pcm)[off + s] * (1.0 / 32768.0)
                                        : (double)((const float*)c.pcm)[off + s];
     buf[0][j] = double2{v * c.win[j], 0.0};
   }
   const int cur = fft1024(buf, c.tw, tid);
-  double2* dst = c.spec + ((size_t)lc * c.t_max + t) * kBins;
+  double2* dst = c.spec + ((size_t)job * c.t_max + t) * kBins;
   const double scale = 1.0 / (kN / 2);   // 1 / sum(hann(1024, periodic)) = 1 / 512
   for (int f = tid; f < kBins; f += 256) dst[f] = double2{buf[cur][f].x * scale, buf[cur][f].y * scale};
 }
@@ -118,13 +140,13 @@ __global__ __launch_bounds__(256) void clean_stft_kernel(CleanDev c) {
 // scipy.signal.filtfilt([b], [1, b - 1], x, padtype=None): y[n] = b x[n] + (1 - b) y[n-1] started from the steady state
 // of x[0] (lfilter_zi * x[0], i.e. y[0] = x[0]), then the same filter over the reversed result.
 __global__ __launch_bounds__(64) void clean_gate_kernel(CleanDev c) {
-  const int lc = blockIdx.y, clip = c.clip0 + lc, f = blockIdx.x * 64 + threadIdx.x;
-  const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || n > c.max_samples || f >= kBins) return;
-  const int T = frames_of(n, c.padding);
-  const double2* sp = c.spec + (size_t)lc * c.t_max * kBins + f;
-  double* sm = c.smooth + (size_t)lc * c.t_max * kBins + f;
-  double* mk = c.mask + (size_t)lc * c.t_max * kBins + f;
+  const int job = blockIdx.y, f = blockIdx.x * 64 + threadIdx.x;
+  const Job jb = job_of(c, job / c.nch, job % c.nch);
+  if (!jb.ok || f >= kBins) return;
+  const int T = jb.T;
+  const double2* sp = c.spec + (size_t)job * c.t_max * kBins + f;
+  double* sm = c.smooth + (size_t)job * c.t_max * kBins + f;
+  double* mk = c.mask + (size_t)job * c.t_max * kBins + f;
   const double b = c.b, a = 1.0 - b;
   double y = 0.0;
   for (int t = 0; t < T; ++t) {
@@ -146,26 +168,26 @@ __global__ __launch_bounds__(64) void clean_gate_kernel(CleanDev c) {
 // Zero-boundary "same" convolution of the mask with the triangle filter, which is an outer product: a pass along
 // frequency into the (now free) smoother buffer, a pass along time, then X *= mask * prop + (1 - prop).
 __global__ __launch_bounds__(256) void clean_blur_freq_kernel(CleanDev c) {
-  const int lc = blockIdx.z, clip = c.clip0 + lc, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
-  const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || n > c.max_samples || f >= kBins || t >= frames_of(n, c.padding)) return;
-  const double* mk = c.mask + ((size_t)lc * c.t_max + t) * kBins;
+  const int job = blockIdx.z, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  const Job jb = job_of(c, job / c.nch, job % c.nch);
+  if (!jb.ok || f >= kBins || t >= jb.T) return;
+  const double* mk = c.mask + ((size_t)job * c.t_max + t) * kBins;
   const int hf = c.nf / 2;
   double row = 0.0;
   for (int df = -hf; df <= hf; ++df) {
     const int ff = f + df;
     if (ff >= 0 && ff < kBins) row += mk[ff] * c.wf[hf - df];
   }
-  c.smooth[((size_t)lc * c.t_max + t) * kBins + f] = row;
+  c.smooth[((size_t)job * c.t_max + t) * kBins + f] = row;
 }
 
 __global__ __launch_bounds__(256) void clean_blur_time_kernel(CleanDev c) {
-  const int lc = blockIdx.z, clip = c.clip0 + lc, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
-  const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || n > c.max_samples || f >= kBins) return;
-  const int T = frames_of(n, c.padding);
+  const int job = blockIdx.z, t = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  const Job jb = job_of(c, job / c.nch, job % c.nch);
+  if (!jb.ok || f >= kBins) return;
+  const int T = jb.T;
   if (t >= T) return;
-  const double* rows = c.smooth + (size_t)lc * c.t_max * kBins + f;
+  const double* rows = c.smooth + (size_t)job * c.t_max * kBins + f;
   const int ht = c.nt / 2;
   double acc = 0.0;
   for (int dt = -ht; dt <= ht; ++dt) {
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256) void clean_blur_time_kernel(CleanDev c) {
     if (tt >= 0 && tt < T) acc += rows[(size_t)tt * kBins] * c.wt[ht - dt];
   }
   const double m = (acc * c.inv_tot) * c.prop + (1.0 - c.prop);
-  double2* z = c.spec + ((size_t)lc * c.t_max + t) * kBins + f;
+  double2* z = c.spec + ((size_t)job * c.t_max + t) * kBins + f;
   *z = double2{z->x * m, z->y * m};
 }
 
@@ -181,10 +203,10 @@ __global__ __launch_bounds__(256) void clean_blur_time_kernel(CleanDev c) {
 // does), inverse = conj(forward(conj(.))) / 1024, times sum(window) = 512.
 __global__ __launch_bounds__(256) void clean_istft_kernel(CleanDev c) {
   __shared__ double2 buf[2][kN];
-  const int lc = blockIdx.y, clip = c.clip0 + lc, t = blockIdx.x, tid = threadIdx.x;
-  const long long n = c.offsets[clip + 1] - c.offsets[clip];
-  if (n <= 0 || n > c.max_samples || t >= frames_of(n, c.padding)) return;
-  const double2* src = c.spec + ((size_t)lc * c.t_max + t) * kBins;
+  const int job = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const Job jb = job_of(c, job / c.nch, job % c.nch);
+  if (!jb.ok || t >= jb.T) return;
+  const double2* src = c.spec + ((size_t)job * c.t_max + t) * kBins;
   for (int f = tid; f < kBins; f += 256) {
     double2 z = src[f];
     if (f == 0 || f == kN / 2) z.y = 0.0;
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(256) void clean_istft_kernel(CleanDev c) {
     if (f > 0 && f < kN / 2) buf[0][kN - f] = double2{z.x, z.y};   // conj(Z[1024 - f]) = Z[f]
   }
   const int cur = fft1024(buf, c.tw, tid);
-  double* dst = c.seg + ((size_t)lc * c.t_max + t) * kN;
+  double* dst = c.seg + ((size_t)job * c.t_max + t) * kN;
   for (int j = tid; j < kN; j += 256) dst[j] = buf[cur][j].x * 0.5;   // / 1024 * 512, both exact
 }
 
@@ -203,14 +225,16 @@ __global__ __launch_bounds__(256) void clean_ola_kernel(CleanDev c) {
   const long long off = c.offsets[clip], n = c.offsets[clip + 1] - off;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n || n > c.max_samples) return;
-  const int T = frames_of(n, c.padding);
-  const long long q = i + c.padding;          // index in the padded chunk
+  const int k = n <= c.chunk ? 0 : (int)(i / c.chunk);   // the chunk this sample is cropped from
+  const Job jb = job_of(c, lc, k);
+  const int T = jb.T;
+  const long long q = i - jb.c0 + c.padding;  // index in the padded chunk
   float out = 0.f;
   if (q < (long long)(T - 1) * kHop) {
     const long long p = q + kN / 2;           // index in stft's zero-extended signal
     const int t_hi = (int)std::min<long long>(p / kHop, T - 1);
     const int t_lo = (int)std::max<long long>(0, (p - (kN - 1) + kHop - 1) / kHop);
-    const double* seg = c.seg + (size_t)lc * c.t_max * kN;
+    const double* seg = c.seg + ((size_t)lc * c.nch + k) * c.t_max * kN;
     double x = 0.0, norm = 0.0;
     for (int t = t_lo; t <= t_hi; ++t) {
       const int j = (int)(p - (long long)t * kHop);
@@ -269,6 +293,7 @@ struct Buf {
 
 struct DysfCleaner {
   int device = 0, sr = 16000, padding = 30000;
+  long long chunk = 600000;   // noisereduce's chunk_size default (the reference passes none)
   double b = 0, prop = 1, shift = -2, slope = 10, inv_tot = 1;
   int nf = 1, nt = 1;
   Buf tables, spec, smooth, mask, seg, y, small;
@@ -356,19 +381,23 @@ int32_t dysf_clean_batch_dev(DysfCleaner* c, const void* d_pcm, int32_t pcm_type
   if (!c || !d_pcm || !d_offsets || !d_status || n_clips < 0 || max_samples < 0 || total_samples < 0) { g_clerr = "bad argument"; return DYSF_E_INVALID; }
   if (pcm_type != DYSF_PCM_I16 && pcm_type != DYSF_PCM_F32) { g_clerr = "bad pcm_type"; return DYSF_E_INVALID; }
   if (n_clips == 0) return 0;
-  if (max_samples > 600000) { g_clerr = "clips beyond noisereduce's chunk_size (600000 samples) are not supported"; return DYSF_E_INVALID; }
+  if (max_samples > 0x7ff00000LL) { g_clerr = "clip too long"; return DYSF_E_INVALID; }
   if (hipSetDevice(c->device) != hipSuccess) { g_clerr = "hipSetDevice failed"; return DYSF_E_HIP; }
   hipStream_t s = (hipStream_t)stream;
-  const int t_max = (int)((max_samples + 2LL * c->padding) / kHop) + 1;
-  const size_t per_clip = (size_t)t_max * (kBins * (sizeof(double2) + 2 * sizeof(double)) + kN * sizeof(double));
-  const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_clips, std::min<size_t>(c->ws_budget / per_clip, 65535)));
-  if (!c->spec.reserve((size_t)sub * t_max * kBins * sizeof(double2)) || !c->smooth.reserve((size_t)sub * t_max * kBins * sizeof(double)) ||
-      !c->mask.reserve((size_t)sub * t_max * kBins * sizeof(double)) || !c->seg.reserve((size_t)sub * t_max * kN * sizeof(double)) ||
+  const long long chunk = c->chunk;
+  const int nch = max_samples <= chunk ? 1 : (int)((max_samples - 1) / chunk) + 1;   // gating jobs per clip
+  const int t_max = (int)((std::min<long long>(max_samples, chunk) + 2LL * c->padding) / kHop) + 1;
+  const size_t per_clip = (size_t)nch * t_max * (kBins * (sizeof(double2) + 2 * sizeof(double)) + kN * sizeof(double));
+  const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_clips, std::min<size_t>(c->ws_budget / per_clip, (size_t)(65535 / nch))));
+  const size_t jobs = (size_t)sub * nch;
+  if (nch > 65535) { g_clerr = "clip too long"; return DYSF_E_INVALID; }
+  if (!c->spec.reserve(jobs * t_max * kBins * sizeof(double2)) || !c->smooth.reserve(jobs * t_max * kBins * sizeof(double)) ||
+      !c->mask.reserve(jobs * t_max * kBins * sizeof(double)) || !c->seg.reserve(jobs * t_max * kN * sizeof(double)) ||
       !c->small.reserve((size_t)n_clips * sizeof(unsigned)) || (!d_denoised && !c->y.reserve((size_t)std::max<int64_t>(total_samples, 1) * sizeof(float)))) {
     g_clerr = "out of device memory for the cleaning workspace"; return DYSF_E_NOMEM;
   }
   CleanDev d{};
-  d.pcm = d_pcm; d.offsets = (const long long*)d_offsets; d.pcm_type = pcm_type; d.padding = c->padding; d.t_max = t_max; d.max_samples = max_samples;
+  d.pcm = d_pcm; d.offsets = (const long long*)d_offsets; d.pcm_type = pcm_type; d.padding = c->padding; d.chunk = chunk; d.nch = nch; d.t_max = t_max; d.max_samples = max_samples;
   d.b = c->b; d.shift = c->shift; d.slope = c->slope; d.prop = c->prop; d.nf = c->nf; d.nt = c->nt; d.inv_tot = c->inv_tot;
   d.tw = c->d_tw; d.win = c->d_win; d.wf = c->d_wf; d.wt = c->d_wt;
   d.spec = (double2*)c->spec.p; d.smooth = (double*)c->smooth.p; d.mask = (double*)c->mask.p; d.seg = (double*)c->seg.p;
@@ -379,11 +408,11 @@ int32_t dysf_clean_batch_dev(DysfCleaner* c, const void* d_pcm, int32_t pcm_type
     const int m = std::min(sub, n_clips - c0);
     d.clip0 = c0;
     hipLaunchKernelGGL(clean_init_kernel, dim3((m + 255) / 256), dim3(256), 0, s, d, m);
-    hipLaunchKernelGGL(clean_stft_kernel, dim3(t_max, m), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(clean_gate_kernel, dim3((kBins + 63) / 64, m), dim3(64), 0, s, d);
-    hipLaunchKernelGGL(clean_blur_freq_kernel, dim3((kBins + 255) / 256, t_max, m), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(clean_blur_time_kernel, dim3((kBins + 255) / 256, t_max, m), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(clean_istft_kernel, dim3(t_max, m), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(clean_stft_kernel, dim3(t_max, m * nch), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(clean_gate_kernel, dim3((kBins + 63) / 64, m * nch), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(clean_blur_freq_kernel, dim3((kBins + 255) / 256, t_max, m * nch), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(clean_blur_time_kernel, dim3((kBins + 255) / 256, t_max, m * nch), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(clean_istft_kernel, dim3(t_max, m * nch), dim3(256), 0, s, d);
     if (sample_blocks) {
       hipLaunchKernelGGL(clean_ola_kernel, dim3(sample_blocks, m), dim3(256), 0, s, d);
       if (d_normalized || d_pcm16) hipLaunchKernelGGL(clean_quant_kernel, dim3(sample_blocks, m), dim3(256), 0, s, d);

@@ -15,6 +15,7 @@ pipeline1.py:447-456 "Feature extraction"), with the reference's memoisation con
 Inputs must be decodable by ``load_audio`` (mono PCM_16 WAV; MP3 decode is upstream of this path).  Row keys are those of
 the dicts pipeline1.py:401-412 appends.  No CPU implementation of any numeric step here."""
 import csv
+import logging
 import os
 from typing import Dict, List, Optional, Sequence
 
@@ -66,11 +67,23 @@ def preprocess_files(files: Sequence[str], clear_dir: str = CLEAR_DIR, batch: in
         first = {}
         todo = [i for i in todo if first.setdefault(cleaned_paths[i], i) == i]
         if todo:
-            res = get_cleaner(TARGET_SR, device, prop_decrease).clean_batch([group[i][1] for i in todo], pcm16=True)
             os.makedirs(clear_dir, exist_ok=True)
-            for k, i in enumerate(todo):
-                if int(res["status"][k]) == 0:
-                    write_wav_pcm16(cleaned_paths[i], res["pcm16"][k], TARGET_SR)
+            cleaner = get_cleaner(TARGET_SR, device, prop_decrease)
+            try:   # one launch for the whole batch; clips beyond noisereduce's chunk_size are gated chunk by chunk inside
+                res = cleaner.clean_batch([group[i][1] for i in todo], pcm16=True)
+                done = [(i, int(res["status"][k]), res["pcm16"][k]) for k, i in enumerate(todo)]
+            except Exception as e:   # e.g. the batch's workspace does not fit: file by file, as the reference works (p1:384)
+                logging.error(f"batched cleaning failed, cleaning file by file: {e}")
+                done = []
+                for i in todo:
+                    try:
+                        r = cleaner.clean_batch([group[i][1]], pcm16=True)
+                        done.append((i, int(r["status"][0]), r["pcm16"][0]))
+                    except Exception as e1:   # p1:144-146: "Cleaning failed" -> the original path is used (p1:386-388)
+                        logging.error(f"Cleaning failed for {group[i][0]}: {e1}")
+            for i, status, pcm in done:
+                if status == 0:
+                    write_wav_pcm16(cleaned_paths[i], pcm, TARGET_SR)
         clean_audio = []
         for i, (f, y_raw, _) in enumerate(group):
             path = cleaned_paths[i] if os.path.exists(cleaned_paths[i]) else f        # p1:386-388: fall back to the original

@@ -1263,3 +1263,24 @@ def test_deployed_predictor_with_the_served_forest(golden_dir, tmp_path):
         n += 1
     assert n >= 12
     rf.close()
+
+
+def test_cleaning_long_clips_are_gated_in_noisereduce_chunks():
+    """Clips beyond noisereduce's chunk_size (600 000 samples = 37.5 s at 16 kHz) -- the reference's 126.5 s sidebar uploads
+    went through main1.py:598-611 like this -- are gated in full 600 000-sample spans, each inside its 30 000 real
+    neighbouring samples, and the spans concatenated (SpectralGate.get_traces).  A mixed batch (short, exactly one chunk,
+    one sample over, two and a bit chunks) against the oracle's chunk loop: float32 signal to 1e-6 of its peak, int16
+    samples equal up to two one-LSB differences per clip."""
+    lens = [26000, 600000, 600001, 1250000]
+    clips = [_noisy(60 + i, n) for i, n in enumerate(lens)]
+    cl = rsd_amd.AudioCleaner(sr=16000, device=0, prop_decrease=0.8)
+    res = cl.clean_batch(clips, denoised=True, pcm16=True)
+    assert res["status"].tolist() == [0, 0, 0, 0]
+    for i, y in enumerate(clips):
+        ref = CO.reduce_noise(y, 16000, 0.8)
+        assert ref.shape == y.shape
+        assert np.abs(res["denoised"][i].astype(np.float64) - ref).max() <= 1e-6 * np.abs(ref).max(), lens[i]
+        want = CO.float_to_pcm16(CO.normalize(ref))
+        d = np.abs(res["pcm16"][i].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and int((d != 0).sum()) <= 2, (lens[i], int(d.max()), int((d != 0).sum()))
+    cl.close()

@@ -262,3 +262,30 @@ def test_deployed_models_fixture_reproduces_the_reference_cv_table(golden_dir):
     assert (z["rf_pred"] == z["y"]).sum() >= 905 - 17
     tun = json.load(open(os.path.join(golden_dir, "tuning_888.json")))["tuning_index"]
     assert len(tun) == 888 and all(0 <= v < 100 for v in tun.values())
+
+
+def test_clean_oracle_chunk_loop_follows_noisereduce(monkeypatch):
+    """oracle/dysf_clean_oracle.reduce_noise beyond chunk_size (SpectralGate.get_traces): every chunk is the full span
+    [k c, (k + 1) c) gated inside `padding` real neighbouring samples -- so a chunk's output depends on nothing outside
+    [k c - padding, (k + 1) c + padding) -- and clips up to chunk_size take the single-chunk path unchanged.  Run with a
+    small chunk_size / padding so that it is fast."""
+    monkeypatch.setattr(CO, "CHUNK_SIZE", 6000)
+    monkeypatch.setattr(CO, "PADDING", 1500)
+    rng = np.random.default_rng(3)
+    y = (0.1 * rng.standard_normal(6000 * 2 + 2500)).astype(np.float32)
+    out = CO.reduce_noise(y, 16000, 0.8)
+    assert out.shape == y.shape and out.dtype == np.float32 and np.isfinite(out).all()
+    # chunk 0 does not see samples at or beyond 6000 + 1500
+    y2 = y.copy(); y2[7500:] = 0
+    assert np.array_equal(CO.reduce_noise(y2, 16000, 0.8)[:6000], out[:6000])
+    # chunk 2 (the last, partial one) does not see samples before 12000 - 1500
+    y3 = y.copy(); y3[:10500] = 0
+    assert np.array_equal(CO.reduce_noise(y3, 16000, 0.8)[12000:], out[12000:])
+    # ... and is the crop of the full-span chunk read past the end as zeros
+    chunk = np.zeros(6000 + 2 * 1500); chunk[:1500 + 2500] = y[10500:]
+    want = CO.spectral_gate_nonstationary(chunk, 16000, 0.8)[1500:1500 + 2500].astype(np.float32)
+    assert np.array_equal(out[12000:], want)
+    # exactly chunk_size: one chunk between zeros
+    y1 = y[:6000]
+    c1 = np.zeros(6000 + 3000); c1[1500:7500] = y1
+    assert np.array_equal(CO.reduce_noise(y1, 16000, 0.8), CO.spectral_gate_nonstationary(c1, 16000, 0.8)[1500:7500].astype(np.float32))
