@@ -419,7 +419,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   // ---- kernel A2 (wave-private STFT + mel): the throughput presets at n_fft 512
   const bool use_a2 = h->stft_variant != 1 && p.n_fft == 512 && !p.parity && !p.chroma && !dbg_S && !d_metrics &&
                       p.hop <= 4096;
-  int a2_qpw = 0, a2_groups = 0, a2_nw = 4, a2_occ = 5;
+  int a2_qpw = 0, a2_groups = 0, a2_nw = 8, a2_occ = 6;
   size_t lds_a2 = 0;
   if (use_a2) {
     if (!h->mel4_steps) {
@@ -432,16 +432,26 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     }
     a.mel4_pack = (const float*)h->d_mel4_pack.p; a.mel4_kbeg = (const int*)h->d_mel4_kbeg.p;
     a.mel4_steps = h->mel4_steps; a.mel4_rounds = h->mel4_rounds;
-    if (const char* e = std::getenv("DYSF_A2_NW")) a2_nw = std::atoi(e) == 8 ? 8 : 4;
-    if (const char* e = std::getenv("DYSF_A2_OCC")) a2_occ = std::max(4, std::min(6, std::atoi(e)));
+    if (const char* e = std::getenv("DYSF_A2_NW")) { const int v = std::atoi(e); if (v == 4 || v == 5 || v == 6 || v == 8) a2_nw = v; }
+    if (a2_nw == 5) a2_occ = 5;
+    if (a2_nw == 6) a2_occ = 6;
+    if (const char* e = std::getenv("DYSF_A2_OCC")) { if (a2_nw == 4 || a2_nw == 8) a2_occ = std::max(4, std::min(6, std::atoi(e))); }
+    if (a2_nw == 8 && a2_occ == 5) a2_occ = 4;
     const int tab_floats = 16 * 84 + h->mel4_rounds * h->mel4_steps * 2 * 64;
     lds_a2 = (size_t)(a2_nw * kA2Region + tab_floats) * 4;
-    // the occupancy the build is compiled for must fit the CU's LDS; step down otherwise (wider mel banks)
-    while (a2_occ > 4 && lds_a2 * (size_t)(4 * a2_occ / a2_nw) > h->lds_limit) --a2_occ;
-    // a wave walks ~19 consecutive quads (a 3 s clip at hop 160 is one 4-wave workgroup); longer clips take more workgroups
-    a2_qpw = a2_nw == 8 ? 10 : 19;
-    if (const char* e = std::getenv("DYSF_QUADS")) { if (std::atoi(e) > 0) a2_qpw = std::atoi(e); }
+    // the occupancy a 4-wave build is compiled for must fit the CU's LDS; step down otherwise (wider mel banks)
+    while (a2_nw == 4 && a2_occ > 4 && lds_a2 * (size_t)a2_occ > h->lds_limit) --a2_occ;
+    // Quads per wave: the longest clip is cut into G workgroups of NW waves with about six quads per wave -- more, smaller
+    // workgroups than the CUs hold at once, so that they start at different times (waves that run this program in phase
+    // -- all in their VALU passes, then all in their LDS / MFMA passes -- are measurably slower: 120 vs 127-134 us same-box
+    // between geometries that differ only in this), and no wave of the last workgroup sits idle (76 quads of a 3 s clip at
+    // hop 160: 2 workgroups x 8 waves x 5 quads).
     const int64_t nq_max = (t_max + 3) / 4;
+    {
+      const int64_t g = std::max<int64_t>(1, (nq_max + 3 * a2_nw) / (6 * a2_nw));
+      a2_qpw = (int)std::max<int64_t>(1, (nq_max + g * a2_nw - 1) / (g * a2_nw));
+    }
+    if (const char* e = std::getenv("DYSF_QUADS")) { if (std::atoi(e) > 0) a2_qpw = std::atoi(e); }
     a2_groups = (int)((nq_max + a2_nw * a2_qpw - 1) / (a2_nw * a2_qpw));
     a.quads_per_wave = a2_qpw;
     a.stagger_mode = 0; a.stagger_units = 6;

@@ -2077,10 +2077,14 @@ static hipError_t launch_a2(const KArgs& a, int pcm_type, dim3 grid, size_t lds_
 }
 hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, int waves_per_wg, int waves_per_simd, dim3 grid, size_t lds_bytes,
                                 hipStream_t s) {
+  // builds: (waves per workgroup, waves per SIMD the registers allow) -- 4 workgroups of 4 / 5 / 6 waves per CU, or 8-wave
+  // workgroups at 4 or 6 waves per SIMD
   if (waves_per_wg == 8) {
     if (waves_per_simd >= 6) return launch_a2<8, 6>(a, pcm_type, grid, lds_bytes, s);
     return launch_a2<8, 4>(a, pcm_type, grid, lds_bytes, s);
   }
+  if (waves_per_wg == 6) return launch_a2<6, 6>(a, pcm_type, grid, lds_bytes, s);
+  if (waves_per_wg == 5) return launch_a2<5, 5>(a, pcm_type, grid, lds_bytes, s);
   if (waves_per_simd >= 6) return launch_a2<4, 6>(a, pcm_type, grid, lds_bytes, s);
   if (waves_per_simd == 5) return launch_a2<4, 5>(a, pcm_type, grid, lds_bytes, s);
   return launch_a2<4, 4>(a, pcm_type, grid, lds_bytes, s);
