@@ -15,10 +15,13 @@ Workloads (BASELINE.json `configs`):
   --config 4         configs[3]: 100 000 clips (clip j = bank clip j mod 1024) sharded contiguously over the ranks
                      (12 500 per GPU at N = 8), resident; pooled rows -> MLP head -> one all-gather of [n_local, 3]; the
                      gathered arg-max is checked against the single-GPU result of the bank.  Strong scaling.
-  --config 5         configs[4]: per GPU 1024 clips of 1-10 s at 22.05 kHz (lengths ~ U[1, 10] s, seed 4321 + rank), 2048-pt STFT
-                     hop 512, 128 mels, 20 MFCC + delta + delta2; the clips are grouped by ceil(seconds) into 10 buckets, each
-                     bucket is one ragged launch padded to its own longest clip (frame rows [n_b, 60, T_b]) followed by the
-                     CNN head in float16 MFMA with the clips' true widths; logits are put back in clip order and all-gathered.
+  --config 5         configs[4]: ONE list of 1024 x N clips of 1-10 s at 22.05 kHz (lengths ~ U[1, 10] s, seed 4321), cut into
+                     contiguous shards balanced by cumulative sample count (SURVEY 8e: rsd_amd.pipeline.shard_by_samples);
+                     2048-pt STFT hop 512, 128 mels, 20 MFCC + delta + delta2; every rank groups ITS clips by ceil(seconds)
+                     into 10 buckets, each bucket is one ragged launch padded to its own longest clip (frame rows
+                     [n_b, 60, T_b]) followed by the CNN head in float16 MFMA with the clips' true widths; logits go back
+                     into clip order, one all-gather of the (unequal) shards, and the gathered arg-max is checked against
+                     a single-GPU pass over the whole list.
   --preset reference_149   the reference's own parameterisation (2048 / 512 / 128 mels / 20 MFCC + chroma, parity mode)
                      on the same 1024 clips per GPU: pooled 144-d rows + tuning index -> MLP(149 -> 128 -> 64 -> 3).
 
@@ -123,6 +126,8 @@ def parse_args():
     ap.add_argument("--head", default="mlp", choices=("mlp", "cnn"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive measurement (N = 1 only)")
+    ap.add_argument("--no-reference-leg", action="store_true",
+                    help="skip the short REFERENCE_149 leg (config.reference_149) the default run adds after its timed region")
     ap.add_argument("--eager-head", action="store_true",
                     help="run the MLP head as the eager torch module instead of the one-kernel HIP head (dysf_mlp_*)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -173,7 +178,7 @@ def main():
 
     import rsd_amd
     from rsd_amd.classifier import FusedMLPHead, MLPHead
-    from rsd_amd.pipeline import LaneExecutor, gather_rows, shard_range
+    from rsd_amd.pipeline import LaneExecutor, gather_rows, gather_rows_by_bounds, shard_by_samples, shard_range
     from rsd_amd.synth import synth_bank
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,9 +193,11 @@ def main():
     # host-only work first (process pools fork; keep that ahead of any GPU initialisation)
     workers = args.bank_workers or max(1, min(8, len(os.sched_getaffinity(0)) // max(1, world)))
     bank = synth_bank(BATCH, N_SAMPLES, 16000, workers=workers)
-    cpu = None
+    cpu = cpu149 = None
     if world == 1 and not args.no_cpu_baseline and args.config != 5:
         cpu = cpu_baseline(bank[:256], args.preset)
+        if args.config == 2 and args.preset == "bench_512" and args.head == "mlp" and not args.no_reference_leg:
+            cpu149 = cpu_baseline(bank[:256], "reference_149", budget_s=8.0)   # for config.reference_149
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -218,22 +225,34 @@ def main():
         if args.preset != "bench_512" or args.head != "mlp":
             raise SystemExit("--config 5 fixes its own parameters (2048 / 512 / 128 mels at 22.05 kHz) and head (CNN, float16 MFMA)")
         sr5 = 22050
-        rng5 = np.random.default_rng(4321 + rank)
-        lens = (rng5.uniform(1.0, 10.0, size=BATCH) * sr5).astype(np.int64)
-        sec = np.minimum(10, np.ceil(lens / sr5).astype(np.int64))
-        src = torch.from_numpy(bank.reshape(-1)).to(dev)             # 49 M samples of synthetic audio to cut the clips from
-        buckets = []
-        for b in range(1, 11):
-            idx = np.nonzero(sec == b)[0]
-            if len(idx) == 0:
-                continue
-            bl = lens[idx]
-            starts = rng5.integers(0, src.numel() - int(bl.max()), size=len(idx))
-            boff = np.concatenate([[0], np.cumsum(bl)]).astype(np.int64)
-            bpcm = torch.cat([src[int(s0):int(s0) + int(n)] for s0, n in zip(starts, bl)])
-            buckets.append({"idx": torch.from_numpy(idx).to(dev), "pcm": bpcm, "off": torch.from_numpy(boff).to(dev),
+        # one global clip list (seed 4321): lengths, and where in the 49 M samples of synthetic audio each clip is cut from
+        total = BATCH * world
+        rng5 = np.random.default_rng(4321)
+        lens_all = (rng5.uniform(1.0, 10.0, size=total) * sr5).astype(np.int64)
+        src5 = torch.from_numpy(bank.reshape(-1)).to(dev)
+        starts_all = rng5.integers(0, src5.numel() - int(lens_all.max()), size=total)
+        bounds5 = shard_by_samples(lens_all, world)          # contiguous shards, balanced by cumulative sample count
+        lo, n_local = int(bounds5[rank]), int(bounds5[rank + 1] - bounds5[rank])
+
+        def make_buckets(first, count):
+            """Clips [first, first + count) of the list grouped by ceil(seconds): resident PCM + offsets per bucket; `idx` is
+            the clip's position inside the range."""
+            ln, st = lens_all[first:first + count], starts_all[first:first + count]
+            sec = np.minimum(10, np.ceil(ln / sr5).astype(np.int64))
+            out = []
+            for b in range(1, 11):
+                idx = np.nonzero(sec == b)[0]
+                if len(idx) == 0:
+                    continue
+                bl = ln[idx]
+                boff = np.concatenate([[0], np.cumsum(bl)]).astype(np.int64)
+                bpcm = torch.cat([src5[int(s0):int(s0) + int(n)] for s0, n in zip(st[idx], bl)])
+                out.append({"idx": torch.from_numpy(idx).to(dev), "pcm": bpcm, "off": torch.from_numpy(boff).to(dev),
                             "max": int(bl.max()), "n": len(idx), "samples": int(bl.sum())})
-        total_samples5 = int(lens.sum())
+            return out
+        buckets = make_buckets(lo, n_local)
+        lens = lens_all[lo:lo + n_local]
+        total_samples5 = int(lens_all.sum())
     params = rsd_amd.REFERENCE_149 if args.preset == "reference_149" else rsd_amd.BENCH_512
     if args.config == 5:
         params = rsd_amd.FeatureParams(sr=22050, chroma=False, parity=False)   # 2048 / 512 / 128 mels / 20 MFCC, librosa defaults
@@ -277,11 +296,11 @@ def main():
         res["logits"] = run_head(res)
         res["all_logits"] = gather_rows(res["logits"], total, rank, world)
 
-    def step5():
-        """configs[4]: one ragged launch + CNN per length bucket, logits scattered back into clip order, one all-gather."""
-        logits = torch.empty((BATCH, 3), dtype=torch.float32, device=dev)
-        status = torch.empty(BATCH, dtype=torch.int32, device=dev)
-        for i, b in enumerate(buckets):
+    def run_buckets(bks, n_rows):
+        """One ragged launch + CNN per length bucket (lanes alternate), logits scattered back into clip order."""
+        logits = torch.empty((n_rows, 3), dtype=torch.float32, device=dev)
+        status = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        for i, b in enumerate(bks):
             k = i % n_lanes
             with torch.cuda.stream(lanes.streams[k]):
                 r = lanes.extractors[k].extract_batch_device(b["pcm"], b["off"], b["max"], pooled=False, frames=True)
@@ -292,9 +311,12 @@ def main():
                     t.record_stream(lanes.streams[k])
         lanes.join()
         lanes.fork()
-        res = {"logits": logits, "status": status}
-        res["all_logits"] = gather_rows(logits, total, rank, world)
-        return res
+        return logits, status
+
+    def step5():
+        """configs[4]: this rank's shard of the list, bucket by bucket, then the one all-gather of the (unequal) shards."""
+        logits, status = run_buckets(buckets, n_local)
+        return {"logits": logits, "status": status, "all_logits": gather_rows_by_bounds(logits, bounds5, rank, world)}
 
     def step():
         if args.config == 5:
@@ -436,8 +458,70 @@ def main():
             got = all_logits.argmax(dim=1)
             argmax_ok = bool(torch.equal(got, ref[torch.arange(total, device=dev) % BATCH]))
             assert argmax_ok, "gathered arg-max differs from the single-GPU result"
+        logits_close = None
+        if args.config == 5:
+            # configs[4]: a single-GPU pass over the WHOLE list (its buckets hold other clips and are padded to other widths
+            # than the shards' buckets) must give the gathered result.  A clip's features and CNN output do not depend on
+            # its batch neighbours; the float16 head's partial sums may be ordered differently, hence the arg-max is
+            # compared where the two leading logits are more than 1e-3 apart and the logits within 1e-3.
+            all_buckets = make_buckets(0, total)   # (built on the main stream:
+            lanes.fork()                            #  the lanes must not start before it is there)
+            ref_logits, _ = run_buckets(all_buckets, total)
+            lanes.join()
+            torch.cuda.synchronize(dev)
+            top2 = torch.topk(ref_logits, 2, dim=1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+            logits_close = float((all_logits - ref_logits).abs().max())
+            argmax_ok = bool(torch.equal(all_logits.argmax(dim=1)[clear], ref_logits.argmax(dim=1)[clear])) and logits_close <= 1e-3
+            assert argmax_ok, f"gathered logits differ from the single-GPU pass over the whole list (max |d| {logits_close})"
     assert int(res["status"].abs().sum()) == 0 and all_logits.shape == (total, 3), (int(res["status"].abs().sum()), all_logits.shape)
     assert bool(torch.isfinite(all_logits).all())
+    # The reference's own parameterisation (pipeline1.py:216-228) as a short extra leg of the default run, outside the timed
+    # region: the same 1024 clips through REFERENCE_149 (parity mode) + MLP(149), W 20 / K 50 on the lanes.
+    ref149 = None
+    if world == 1 and args.config == 2 and args.preset == "bench_512" and cnn is None and not args.no_reference_leg:
+        p149 = rsd_amd.REFERENCE_149
+        ex149 = rsd_amd.FeatureExtractor(p149, local_rank)
+        lanes149 = LaneExecutor(p149, local_rank, n_lanes, head=None, first_extractor=ex149)
+        d149 = [p149.total_feature_len, 128, 64, 3]
+        head149 = FusedMLPHead(np.zeros(d149[0]), np.ones(d149[0]), [rng.standard_normal((d149[i], d149[i + 1])) / np.sqrt(d149[i]) for i in range(3)],
+                               [np.zeros(d149[i + 1]) for i in range(3)], device=local_rank)
+
+        def after149(r):
+            x = r["pooled"]
+            r["logits"] = head149(torch.cat([x, x.new_zeros((x.shape[0], d149[0] - x.shape[1]))], dim=1))
+
+        with torch.no_grad():
+            lanes149.fork()
+            for _ in range(20):
+                lanes149.submit(pcm, offsets, N_SAMPLES, after=after149, pooled=True, tuning=True)
+            lanes149.join()
+            torch.cuda.synchronize(dev)
+            t149 = time.perf_counter()
+            lanes149.fork()
+            for _ in range(50):
+                r149 = lanes149.submit(pcm, offsets, N_SAMPLES, after=after149, pooled=True, tuning=True)
+            lanes149.join()
+            torch.cuda.synchronize(dev)
+            t149 = time.perf_counter() - t149
+            assert int(r149["status"].abs().sum()) == 0
+            ex149.kernel_timing(True)
+            pk = []
+            for _ in range(6):
+                ex149.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, tuning=True)
+                pk.append(ex149.kernel_timing(True))
+            ex149.kernel_timing(False)
+        km = {k: float(np.median([q[k] for q in pk])) for k in ("stft_mel", "mfcc", "chroma")}
+        b149 = 2 * N_SAMPLES + 4 * ex149.pooled_dim
+        kp = km["stft_mel"] + km["mfcc"] + km["chroma"]
+        ref149 = {"what": "pipeline1.py:216-228 parameterisation (2048 / 512 / 128 mels / 20 MFCC + deltas + chroma_stft with its tuning estimate, "
+                          "parity mode) on the same 1024 resident clips + MLP(149 -> 128 -> 64 -> 3); W 20 / K 50 after the timed region",
+                  "clips_per_s": round(BATCH * 50 / t149, 1), "ms_per_step": round(t149 / 50 * 1e3, 4),
+                  "kernel_ms": {"dysf_stft_mel_kernel": round(km["stft_mel"], 4), "dysf_mfcc_kernel": round(km["mfcc"], 4),
+                                "dysf_chroma_kernel": round(km["chroma"], 4)},
+                  "bytes_per_clip": b149, "achieved_gbs": round(BATCH * b149 / (kp * 1e-3) / 1e9, 1),
+                  "frac": round(BATCH * b149 / (kp * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        del lanes149, ex149
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -453,10 +537,17 @@ def main():
         k_stft, k_mfcc, k_chroma = med("stft_mel"), med("mfcc"), med("chroma")
         k_path = k_stft + k_mfcc + (k_chroma if params.chroma else 0.0)
         achieved = algo_bytes / (k_path * 1e-3) / 1e9
+        # useful arithmetic of the path: FFT 2.5 n log2 n per frame, the non-zero mel taps, the DCT
+        import math
+        n_bins = params.n_fft // 2 + 1
+        mel_nnz = int(np.count_nonzero(ex.table(1))) if hasattr(ex, "table") else params.n_mels * n_bins
+        useful_flops = BATCH * T * (2.5 * params.n_fft * math.log2(params.n_fft) + 2 * mel_nnz + 2 * params.n_mfcc * params.n_mels)
+        a2 = params.n_fft == 512 and not params.parity and not params.chroma and os.environ.get("DYSF_STFT") != "1"
+        stft_name = "dysf_stft_mel_wave_kernel" if a2 else "dysf_stft_mel_kernel"
         # hardware counters are collected in separate rocprofv3 --pmc passes (tools/pmc.sh) and committed with the id
         # of the kernel sources they were measured on; a stale file is not quoted
         counters = None
-        cpath = os.path.join(ROOT, "profiles", "r02_counters.json")
+        cpath = os.path.join(ROOT, "profiles", "r03_counters.json")
         if os.path.exists(cpath):
             try:
                 c = json.load(open(cpath)).get(args.preset if cnn is None else "cnn")
@@ -496,16 +587,20 @@ def main():
             # HBM is the roofline SURVEY 8d prices this path against: bytes = PCM read once + outputs written once (no
             # intermediates), time = the feature launch's kernels back to back on one stream.  The kernels are NOT bandwidth
             # bound: `limited_by` says what the counters show.
-            "roofline": {"bound": "hbm", "kernel": "feature launch: dysf_stft_mel_kernel + dysf_mfcc_kernel" + (" + dysf_chroma_kernel" if params.chroma else ""),
+            "roofline": {"bound": "hbm", "kernel": "feature launch: " + stft_name + " + dysf_mfcc_kernel" + (" + dysf_chroma_kernel" if params.chroma else ""),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (counters or {}).get("hbm_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_clip": bytes_per_clip, "clips_per_launch": BATCH,
                          "kernel_ms": round(k_path, 4), "measured_copy_gbs": round(copy_gbs, 1),
                          "frac_of_measured_copy_bw": round(achieved / copy_gbs, 4),
                          "limited_by": (counters or {}).get("limited_by", "instruction issue / dependent latency, not HBM (see DESIGN.md section 5)"),
+                         # the other roof: useful float32 arithmetic (FFT butterflies + non-zero mel taps + DCT) against the
+                         # vector / matrix peak -- the path sits at the float32 ridge, so both are reported
+                         "valu": {"useful_flops_per_launch": int(useful_flops), "achieved_tflops": round(useful_flops / (k_path * 1e-3) / 1e12, 2),
+                                  "peak_tflops": MFMA_F32_PEAK_TF, "frac": round(useful_flops / (k_path * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
                          "valu_busy": (counters or {}).get("valu_busy"), "mfma_busy": (counters or {}).get("mfma_busy"),
                          "counters_from": (counters or {}).get("source"),
-                         "kernels": {"dysf_stft_mel_kernel": {"ms": round(k_stft, 4), "algorithmic_bytes": BATCH * 2 * N_SAMPLES,
+                         "kernels": {stft_name: {"ms": round(k_stft, 4), "algorithmic_bytes": BATCH * 2 * N_SAMPLES,
                                                               "achieved_gbs": round(BATCH * 2 * N_SAMPLES / (k_stft * 1e-3) / 1e9, 1)},
                                      "dysf_mfcc_kernel": {"ms": round(k_mfcc, 4), "algorithmic_bytes": BATCH * 4 * out_elems,
                                                           "achieved_gbs": round(BATCH * 4 * out_elems / (k_mfcc * 1e-3) / 1e9, 1)}},
@@ -532,16 +627,23 @@ def main():
                             "10 buckets, one ragged launch per bucket padded to the bucket's longest clip, CNN head in float16 MFMA with the clips' "
                             "true widths, logits back in clip order, (N>1) RCCL all-gather",
                 "sr": sr5, "seed": 4321, "clips_per_bucket": {str(int(np.ceil(b["max"] / sr5))): b["n"] for b in buckets},
-                "samples_per_gpu": total_samples5, "samples_per_clip": None, "frames_per_clip": None,
-                "hours_of_audio_per_s": round(total_samples5 * world / sr5 / 3600 / (dt / args.steps), 1),
+                "shards": "contiguous, balanced by cumulative sample count (rsd_amd.pipeline.shard_by_samples); clips per rank: "
+                          + str([int(bounds5[r + 1] - bounds5[r]) for r in range(world)]),
+                "gathered_logits_max_abs_diff_vs_single_gpu_pass": logits_close,
+                "samples_per_gpu": int(lens.sum()), "samples_total": total_samples5, "samples_per_clip": None, "frames_per_clip": None,
+                "hours_of_audio_per_s": round(total_samples5 / sr5 / 3600 / (dt / args.steps), 1),
                 "feature_launches_ms": round(feat5_ms, 4), "cnn_launches_ms": round(cnn5_ms, 4), "head": "cnn (float16 MFMA conv2)"})
             out["dtype"] = "f16"
             out["roofline"] = {"bound": "mfma", "kernel": "dysf_cnn_* over the ten buckets (conv1 + pool + conv2 + average + linear, per-clip widths)",
                                "achieved": round(tf5, 2), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf5 / MFMA_F16_PEAK_TF, 4),
                                "traffic": None, "algorithmic_flops_per_launch": flops5, "kernel_ms": round(cnn5_ms, 4),
                                "feature_kernels_ms": round(feat5_ms, 4),
-                               "feature_algorithmic_bytes": int(2 * total_samples5 + 4 * 60 * int(T5.sum())),
-                               "feature_achieved_gbs": round((2 * total_samples5 + 4 * 60 * int(T5.sum())) / (feat5_ms * 1e-3) / 1e9, 1)}
+                               "feature_algorithmic_bytes": int(2 * int(lens.sum()) + 4 * 60 * int(T5.sum())),
+                               "feature_achieved_gbs": round((2 * int(lens.sum()) + 4 * 60 * int(T5.sum())) / (feat5_ms * 1e-3) / 1e9, 1)}
+        if ref149 is not None:
+            if cpu149 is not None:
+                ref149["cpu_baseline"] = cpu149
+            out["config"]["reference_149"] = ref149
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -200,6 +200,76 @@ int64_t dysf_debug_table(const DysfHandle* h, int32_t which, int32_t arg, float*
 
 
 #ifdef DYSF_STAMP
+// diagnostic build only: a kernel that leaves its whole dynamic LDS allocation filled with NaN bit patterns (what a kernel of
+// another stream may leave behind on a CU), to expose reads of LDS words a kernel never wrote
+__global__ void dysf_poison_lds_kernel(int words, unsigned* sink) {
+  extern __shared__ unsigned pl[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) pl[i] = 0x7fc00000u | (unsigned)i;
+  __syncthreads();
+  if (threadIdx.x == 0 && pl[words - 1] == 1u) sink[0] = pl[0];
+}
+// ... and one that leaves NaN bit patterns in all 256 vector registers of its waves (what the waves of another kernel may
+// leave in the physical registers a new wave is given): exposes reads of registers a kernel never wrote
+__global__ __launch_bounds__(256) void dysf_poison_vgpr_kernel(unsigned* sink) {
+  unsigned keep = 0x7fc00000u + threadIdx.x;
+  asm volatile(".irp r,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71,72,73,74,75,76,77,78,79,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95,96,97,98,99,100,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115,116,117,118,119,120,121,122,123,124,125,126,127,128,129,130,131,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,150,151,152,153,154,155,156,157,158,159,160,161,162,163,164,165,166,167,168,169,170,171,172,173,174,175,176,177,178,179,180,181,182,183,184,185,186,187,188,189,190,191,192,193,194,195,196,197,198,199,200,201,202,203,204,205,206,207,208,209,210,211,212,213,214,215,216,217,218,219,220,221,222,223,224,225,226,227,228,229,230,231,232,233,234,235,236,237,238,239,240,241,242,243,244,245,246,247,248,249,250,251,252,253,254,255\n\tv_mov_b32 v\\r, %0\n\t.endr\n\ts_nop 4" : : "v"(keep) : "v255", "memory");
+  if (keep == 1u) sink[0] = keep;
+}
+int32_t dysf_debug_poison_vgpr(void* stream, int32_t blocks, void* d_sink) {
+  hipLaunchKernelGGL(dysf_poison_vgpr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)d_sink);
+  return hipGetLastError() == hipSuccess ? 0 : DYSF_E_HIP;
+}
+// ... co-residency stress kernels: which ingredient of the float16 conv2 kernel disturbs a feature kernel on the same CU?
+//   kind 0: barriers + LDS traffic (512 threads), 1: float16 MFMA chain, 2: float32 MFMA chain, 3: ds_read_b128 storm
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 4) void dysf_stress_kernel(int kind, int iters, float* sink) {
+  extern __shared__ float sl[];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  if (kind == 0) {
+    for (int i = 0; i < iters; ++i) {
+      sl[(tid * 17 + i) & 4095] = (float)i;
+      __syncthreads();
+      acc += sl[(tid * 5 + i) & 4095];
+      __syncthreads();
+    }
+  } else if (kind == 1) {
+    h8_t a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.01f * (tid + j)); b[j] = (_Float16)(0.02f * j); }
+    f4_t c = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, d, 0, 0, 0);
+    }
+    acc = c[0] + d[1];
+  } else if (kind == 2) {
+    f4_t c = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(0.01f * tid, 0.5f, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(0.5f, 0.01f * tid, d, 0, 0, 0);
+    }
+    acc = c[0] + d[1];
+  } else {
+    for (int i = tid; i < 8192; i += 512) sl[i] = (float)i;
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+      const float4 v = *(const float4*)(sl + ((tid * 4 + 64 * i) & 8188));
+      acc += v.x + v.w;
+    }
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+int32_t dysf_debug_stress(void* stream, int32_t kind, int32_t blocks, int32_t iters, int32_t lds_bytes, void* d_sink) {
+  (void)hipFuncSetAttribute((const void*)dysf_stress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(dysf_stress_kernel, dim3(blocks), dim3(512), (size_t)lds_bytes, (hipStream_t)stream, kind, iters, (float*)d_sink);
+  return hipGetLastError() == hipSuccess ? 0 : DYSF_E_HIP;
+}
+int32_t dysf_debug_poison_lds(void* stream, int32_t blocks, int32_t bytes, void* d_sink) {
+  (void)hipFuncSetAttribute((const void*)dysf_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipLaunchKernelGGL(dysf_poison_lds_kernel, dim3(blocks), dim3(256), (size_t)bytes, (hipStream_t)stream, bytes / 4, (unsigned*)d_sink);
+  return hipGetLastError() == hipSuccess ? 0 : DYSF_E_HIP;
+}
 // diagnostic build only (not declared in dysf_hip.h): per-phase cycle sums of thread 0 of every workgroup
 int32_t dysf_debug_stamps(DysfHandle* h, uint64_t* out16, int32_t reset) {
   if (!h || h->device < 0) return DYSF_E_INVALID;

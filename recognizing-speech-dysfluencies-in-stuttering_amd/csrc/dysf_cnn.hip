@@ -433,20 +433,22 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   const size_t lds = f32 ? (size_t)(kRowTile + 2) * d.TW * kPixPitch32 * sizeof(float)
                          : (size_t)(kRowTile + 2) * d.TW * kPixPitch * sizeof(_Float16);
   if (lds > 160 * 1024) { g_cerr = "feature map too wide for the LDS tile"; return DYSF_E_INVALID; }
+  size_t lds_launch = lds;
+  if (const char* e = std::getenv("DYSF_CNN_LDS")) lds_launch = std::max(lds, (size_t)std::atoll(e));   // co-residency experiments
   const int which = f32 ? 2 : (m->fused ? 0 : 1);
-  if (lds > m->lds_granted[which]) {  // raised once per kernel, and again only when a wider batch needs more
+  if (lds_launch > m->lds_granted[which]) {  // raised once per kernel, and again only when a wider batch needs more
     const void* fn = f32 ? (const void*)dysf_cnn_conv2_f32_kernel
                          : (m->fused ? (const void*)dysf_cnn_conv2_kernel<true> : (const void*)dysf_cnn_conv2_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch) != hipSuccess) {
       g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
     }
-    m->lds_granted[which] = lds;
+    m->lds_granted[which] = lds_launch;
   }
   const dim3 grid2(d.n_tiles, n);
   if (f32) {
-    hipLaunchKernelGGL(dysf_cnn_conv2_f32_kernel, grid2, dim3(512), lds, stream, d, d_frames, n);
+    hipLaunchKernelGGL(dysf_cnn_conv2_f32_kernel, grid2, dim3(512), lds_launch, stream, d, d_frames, n);
   } else if (m->fused) {
-    hipLaunchKernelGGL(dysf_cnn_conv2_kernel<true>, grid2, dim3(512), lds, stream, d, d_frames, n);
+    hipLaunchKernelGGL(dysf_cnn_conv2_kernel<true>, grid2, dim3(512), lds_launch, stream, d, d_frames, n);
   } else {
     hipLaunchKernelGGL(dysf_cnn_conv1_kernel, dim3((d.PH * d.PW + 255) / 256, n), dim3(256), 0, stream, d, d_frames, n);
     hipLaunchKernelGGL(dysf_cnn_conv2_kernel<false>, grid2, dim3(512), lds, stream, d, d_frames, n);

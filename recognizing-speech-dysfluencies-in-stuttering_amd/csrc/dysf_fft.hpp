@@ -47,12 +47,25 @@ DYSF_HD cf mk(float re, float im) { cf r = {re, im}; return r; }
 // z * (-i) = (im, -re)
 template <class C>
 DYSF_HD C mul_mi(C z) { C s = DYSF_SWAP(z); C r = {s[0], -s[1]}; return r; }
+
 // z * (wr + i wi) with compile-time-constant twiddles: the (-wi, wi) vector is a literal
 template <class C>
 DYSF_HD C cmul_const(C z, double wr, double wi) {
   typedef typename scalar_of<C>::type T;
   const C a = {(T)wr, (T)wr}, b = {(T)-wi, (T)wi};
   return z * a + DYSF_SWAP(z) * b;
+}
+DYSF_HD cf cmul(cf z, cf w);
+// float32 form on the device: the run-time complex multiply below with a literal pair (its operand selections are the ones
+// the co-execution check of add_mi clears; the generic form above compiles to a v_pk_mul_f32 with swapped halves)
+DYSF_HD cf cmul_const(cf z, double wr, double wi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const cf w = {(float)wr, (float)wi};
+  return cmul(z, w);
+#else
+  const cf a = {(float)wr, (float)wr}, b = {(float)-wi, (float)wi};
+  return z * a + DYSF_SWAP(z) * b;
+#endif
 }
 // z * w with a run-time twiddle held in a register pair
 DYSF_HD cf cmul(cf z, cf w) {
@@ -90,12 +103,18 @@ struct FftGeom {
   DYSF_HD static constexpr int ns(int s) { return s == 0 ? 1 : (s == 1 ? 16 : 16 * radix(1)); }
 };
 
-// a + (-i) b and a - (-i) b without materialising (-i) b: the swap and the sign ride on the packed add's op_sel / neg
-// modifiers (the generic form below costs a v_xor and a v_mov per product)
+// a + (-i) b and a - (-i) b without materialising (-i) b: the swap of b's halves and the sign ride on the operand
+// modifiers of ONE packed instruction.  It is a v_pk_fma_f32 with the constant 1.0 (b * 1 + a is exactly a + b), not a
+// v_pk_add_f32: on gfx950 v_pk_add_f32 / v_pk_mul_f32 whose op_sel picks DIFFERENT halves of their two sources
+// (op_sel:[0,1] op_sel_hi:[1,0]) return wrong values while a float16 / bfloat16 MFMA of another wave -- any other kernel
+// sharing the CU, e.g. a GEMM of another stream -- is executing (tools/ubench/coexec.hip: 160 000 of 524 288 results differ
+// beside v_mfma_f32_16x16x32_f16 chains, none beside float32 MFMAs; v_pk_fma_f32 with the same operand selection is not
+// affected, nor are equal-half selections, broadcasts and neg modifiers).  `make check-isa` keeps the form out of the
+// library.
 DYSF_HD cf add_mi(cf a, cf b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   cf r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));  // (ar + bi, ai - br)
+  asm("v_pk_fma_f32 %0, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b));  // (ar + bi, ai - br)
   return r;
 #else
   return a + mul_mi(b);
@@ -104,7 +123,7 @@ DYSF_HD cf add_mi(cf a, cf b) {
 DYSF_HD cf sub_mi(cf a, cf b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   cf r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));  // (ar - bi, ai + br)
+  asm("v_pk_fma_f32 %0, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b));  // (ar - bi, ai + br)
   return r;
 #else
   return a - mul_mi(b);

@@ -18,7 +18,14 @@ namespace dysf {
 
 typedef float c32 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ c32 cmulf(c32 a, c32 b) { return c32{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]}; }
+// a * b as one v_pk_mul_f32 + one v_pk_fma_f32 whose operand selections are safe beside float16 MFMAs of other waves (the
+// plain expression compiles to a v_pk_mul_f32 with mixed source halves: see dysf_fft.hpp add_mi and tools/check_isa.py)
+__device__ __forceinline__ c32 cmulf(c32 a, c32 b) {
+  c32 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));  // (a0 b0, a1 b0)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-a1 b1 + t0, a0 b1 + t1)
+  return r;
+}
 
 // w[n] = exp(-i pi n^2 / N): the exponent is reduced exactly (n^2 mod 2N) before it meets floating point
 __device__ __forceinline__ c32 chirp(long long n, long long N) {
@@ -42,7 +49,9 @@ struct HfArgs {
 
 __global__ __launch_bounds__(256) void hf_prep_kernel(HfArgs h) {
   const int clip = blockIdx.y;
-  const long long off = h.offsets[clip], N = h.offsets[clip + 1] - off;
+  const long long off = h.offsets[clip];
+  long long N = h.offsets[clip + 1] - off;
+  if (2 * N - 1 > h.M) N = 0;   // a clip beyond the caller's max_samples: the chirp convolution would alias -- rejected like an empty one
   c32* a = h.a0 + (size_t)clip * h.M;
   c32* b = h.b0 + (size_t)clip * h.M;
   for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < h.M; m += (long long)gridDim.x * 256) {
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void hf_finish_kernel(HfArgs h, const c32* con
   const int clip = blockIdx.x, tid = threadIdx.x;
   const long long off = h.offsets[clip], N = h.offsets[clip + 1] - off;
   float* out = h.metrics + (size_t)clip * 3 + 2;
-  if (N <= 0 || h.flags[clip]) { if (tid == 0) *out = 0.f; return; }
+  if (N <= 0 || 2 * N - 1 > h.M || h.flags[clip]) { if (tid == 0) *out = 0.f; return; }   // (too long for M: see hf_prep_kernel)
   const c32* c = conv + (size_t)clip * h.M;
   // np.fft.rfftfreq(N, 1 / sr): k * (1 / (N * d)) with d = 1 / sr, all float64
   const double val = 1.0 / ((double)N * (1.0 / (double)h.sr));

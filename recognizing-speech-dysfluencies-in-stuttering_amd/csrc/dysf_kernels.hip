@@ -1041,26 +1041,25 @@ __global__ __launch_bounds__(64 * NW, OCC) void dysf_stft_mel_wave_kernel(const 
     // un-packing: register p of lane ls holds Z[ls + 16 p]; Z[NC - k] sits in register 15 - i of lane 16 - ls (lane 0
     // pairs with itself, one register on): row_mirror + row_ror:1, as in kernel A
     __builtin_amdgcn_sched_barrier(0);
-    cf vtw[9];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {   // two bin pairs per 16-byte read of the lane's un-packing twiddles
       const float4 w = ptwr[j];
-      vtw[2 * j] = mk(w.x, w.y); vtw[2 * j + 1] = mk(w.z, w.w);
-    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      cf zm;
+      for (int i = 2 * j; i < 2 * j + 2; ++i) {
+        cf zm;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float offer;
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
-        const int m = __builtin_amdgcn_mov_dpp(__float_as_int(offer), 0x140, 0xf, 0xf, true);
-        zm[h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
+        for (int h = 0; h < 2; ++h) {
+          float offer;
+          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(offer) : "v"(z[15 - i][h]), "v"(z[(16 - i) & 15][h]), "s"(lane0));
+          const int m = __builtin_amdgcn_mov_dpp(__float_as_int(offer), 0x140, 0xf, 0xf, true);
+          zm[h] = __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
+        }
+        const cf pw = pair_powers(z[i], zm, (i & 1) ? mk(w.z, w.w) : mk(w.x, w.y));
+        const int k = ls + L * i;
+        srow_own[k] = pw[0];
+        srow_own[NC - k] = pw[1];
       }
-      const cf pw = pair_powers(z[i], zm, vtw[i]);
-      const int k = ls + L * i;
-      srow_own[k] = pw[0];
-      srow_own[NC - k] = pw[1];
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);   // (keeps the twiddle reads from being hoisted in one block: registers)
     }
     {  // bin NC/2 pairs with itself: X = 2 conj(Z) (V = -1), |X|^2 = 4 |Z|^2; lane 0 holds it
       const cf d = z[8] + z[8], m = d * d;

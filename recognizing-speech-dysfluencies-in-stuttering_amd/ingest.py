@@ -52,12 +52,8 @@ def pinned_empty(n: int, dtype=np.int16) -> np.ndarray:
     the H2D copies of ``StreamingExtractor`` start straight from it."""
     import torch
     t = torch.empty(int(n), dtype={np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]).pin_memory()
-    a = t.numpy()
-    _PINNED_OWNERS[a.ctypes.data] = t     # keeps the allocation alive as long as the process (views carry no owner)
-    return a
-
-
-_PINNED_OWNERS = {}
+    return t.numpy()   # the ndarray (and every view of it) holds a reference to the tensor: the page-locked memory is
+                       # released when the last of them goes away
 
 
 class StreamingExtractor:

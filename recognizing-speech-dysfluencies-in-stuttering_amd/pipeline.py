@@ -39,6 +39,21 @@ def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int, group=
     return out[:n_total]
 
 
+def gather_rows_by_bounds(local: torch.Tensor, bounds, rank: int, world: int, group=None) -> torch.Tensor:
+    """All-gather the row blocks of a partition with unequal shards (``shard_by_samples`` bounds [world + 1]) into
+    [bounds[-1], d] on every rank: shards are padded to the largest one for the single collective."""
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return local
+    sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    assert local.shape[0] == sizes[rank]
+    per = max(sizes)
+    pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * per: r * per + sizes[r]] for r in range(world)], dim=0)
+
+
 class DysfluencyPipeline:
     """extract -> (pooled | frame-level) features -> head -> logits, everything resident on one GPU."""
 

@@ -140,3 +140,19 @@ def test_head_and_resampler_constructors_validate_before_touching_the_gpu():
     assert b"precision" in L.dysf_cnn_last_error()
     assert L.dysf_resampler_create(0, 0, 441, ptr(one), 8, 0, ctypes.byref(h)) < 0 and b"shape" in L.dysf_resampler_last_error()
     assert not h.value
+
+
+def test_device_code_has_no_packed_add_mul_with_mixed_source_halves():
+    """gfx950: v_pk_add_f32 / v_pk_mul_f32 whose op_sel picks different halves of their two sources give wrong results while
+    another wave on the CU executes a float16 / bfloat16 MFMA (tools/ubench/coexec.hip measures it on the GPU; the float16 CNN
+    head on another lane was enough to corrupt the float32 FFT kernels).  The library must not contain that form -- neither
+    hand-written nor produced by the compiler from vector shuffles (tools/check_isa.py disassembles the built library)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(root, "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = os.path.join(root, "recognizing-speech-dysfluencies-in-stuttering_amd", "libdysf_hip.so")
+    seen, bad = mod.check([lib])
+    assert seen == 1, "no gfx950 code objects found in the library"
+    assert not bad, bad[:5]

@@ -117,6 +117,38 @@ def test_logits_all_gather_world_size_2_gloo(n_total):
     assert one.shape == (3, 2)
 
 
+def _gather_bounds_worker(rank, world, port, lens, q):
+    import torch.distributed as dist
+    from rsd_amd.pipeline import gather_rows_by_bounds
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = shard_by_samples(np.array(lens), world)
+    local = torch.arange(int(b[rank]), int(b[rank + 1]), dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0, 100.0])
+    out = gather_rows_by_bounds(local, b, rank, world)
+    q.put((rank, out.numpy(), b.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_shards_all_gather_world_size_2_gloo():
+    """configs[4] at N > 1: shards balanced by cumulative sample count have different clip counts; one all-gather of the
+    padded shards puts every clip's logits back at its index of the global list on every rank."""
+    import torch.multiprocessing as mp
+    from rsd_amd.pipeline import gather_rows_by_bounds
+    lens = [9, 1, 1, 1, 1, 1, 1, 1, 8, 8, 2]   # 34 samples: the first shard holds fewer clips than the second
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_gather_bounds_worker, args=(r, 2, port, lens, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = {r: (o, b) for r, o, b in (q.get(timeout=120) for _ in range(2))}
+    [p.join(timeout=60) for p in procs]
+    want = np.arange(len(lens), dtype=np.float32)[:, None] * np.array([1.0, 10.0, 100.0], np.float32)
+    b = got[0][1]
+    assert b[0] == 0 and b[-1] == len(lens) and b[1] - b[0] != b[2] - b[1]
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)
+    assert gather_rows_by_bounds(torch.ones(3, 2), [0, 3], 0, 1).shape == (3, 2)   # world size 1: a copy
+
+
 def test_mlp_head_reproduces_sklearn_fixture_on_cpu(golden_dir):
     path = os.path.join(golden_dir, "classifier_after.npz")
     z = np.load(path)

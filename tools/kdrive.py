@@ -13,9 +13,10 @@ pcm = torch.from_numpy(bank[np.arange(1024) % 32].reshape(-1)).cuda()
 off = torch.arange(0, 1025, dtype=torch.int64, device="cuda") * 48000
 ex = rsd_amd.FeatureExtractor(preset, 0)
 fr = preset is rsd_amd.BENCH_512
-for _ in range(n): ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=fr)
+fs = int(os.environ.get("KDRIVE_FRAME_STRIDE", "0")) or None
+for _ in range(n): ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=fr, frame_stride=fs)
 torch.cuda.synchronize()
 ex.kernel_timing(True); ts = []
 for _ in range(10):
-    ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=fr); ts.append(ex.kernel_timing(True))
+    ex.extract_batch_device(pcm, off, 48000, pooled=True, frames=fr, frame_stride=fs); ts.append(ex.kernel_timing(True))
 print("stft %.1f us  mfcc %.1f us" % (1e3 * np.median([t["stft_mel"] for t in ts]), 1e3 * np.median([t["mfcc"] for t in ts])))
