@@ -54,6 +54,9 @@ struct DysfHandle {
   double* d_dct_pack = nullptr;
   float* d_dct_pack32 = nullptr;
   double* d_dct_rowsum = nullptr;
+  uint16_t* d_dct_pack16 = nullptr;     // float16 hi / lo split DCT operands (kernel B on the float16 MFMA)
+  double* d_dct_rowsum16 = nullptr;
+  bool dct16 = true;        // DYSF_DCT16=0: keep the DCT of the throughput presets on the float32 MFMA
   int32_t* d_rich_tab = nullptr;
   bool dct64 = false;       // DYSF_DCT64=1: run the DCT on the float64 MFMA instead of the mean-free float32 form
   // workspace / staging
@@ -114,6 +117,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   if (!build_tables(*p, h->t, &err)) { delete h; return fail(DYSF_E_INVALID, err); }
   h->device = device;
   if (const char* e = std::getenv("DYSF_DCT64")) h->dct64 = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DYSF_DCT16")) h->dct16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DYSF_WS_MB")) { if (std::atoll(e) > 0) h->ws_budget = (size_t)std::atoll(e) << 20; }
   if (const char* e = std::getenv("DYSF_STFT")) h->stft_variant = std::atoi(e);
   if (device >= 0) {
@@ -143,6 +147,30 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
     rc |= upload(&h->d_dct_pack, h->t.dct_pack64);
     rc |= upload(&h->d_dct_pack32, h->t.dct_pack32);
     rc |= upload(&h->d_dct_rowsum, h->t.dct_rowsum);
+    if (p->n_mels % 32 == 0 && p->n_mels <= 64) {
+      // D = hi + lo * 2^-11 with hi = float16(D), lo = float16((D - hi) * 2^11): three float16 products (hi x, hi x_lo, lo x)
+      // carry the float32 coefficient to ~2^-22; lo is scaled so that it stays a normal float16
+      const HostTables& t = h->t;
+      const int rbs = t.dct_pack.row_blocks, blks = p->n_mels / 32;
+      std::vector<uint16_t> pk((size_t)rbs * blks * 2 * 64 * 8, 0);
+      std::vector<double> rs((size_t)rbs * 16, 0.0);
+      auto bits = [](_Float16 v) { uint16_t u; std::memcpy(&u, &v, 2); return u; };
+      for (int rb = 0; rb < rbs; ++rb)
+        for (int b = 0; b < blks; ++b)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const int c = rb * 16 + (l & 15), m = 32 * b + 8 * (l >> 4) + j;
+              if (c >= p->n_mfcc || m >= p->n_mels) continue;
+              const float d = t.dct[(size_t)c * p->n_mels + m];
+              const _Float16 hi = (_Float16)d;
+              const _Float16 lo = (_Float16)((d - (float)hi) * 2048.0f);
+              pk[((((size_t)rb * blks + b) * 2 + 0) * 64 + l) * 8 + j] = bits(hi);
+              pk[((((size_t)rb * blks + b) * 2 + 1) * 64 + l) * 8 + j] = bits(lo);
+              rs[c] += (double)(float)hi + (double)(float)lo * (1.0 / 2048.0);
+            }
+      rc |= upload(&h->d_dct_pack16, pk);
+      rc |= upload(&h->d_dct_rowsum16, rs);
+    }
     rc |= upload(&h->d_rich_tab, h->t.rich_tab);
     rc |= upload(&h->d_chroma_pack, h->t.chroma_pack);
     if (rc) { dysf_destroy(h); return DYSF_E_HIP; }
@@ -156,7 +184,7 @@ void dysf_destroy(DysfHandle* h) {
   if (h->device >= 0) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_window); (void)hipFree(h->d_stage_tw); (void)hipFree(h->d_post_tw);
-    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_rich_tab);
+    (void)hipFree(h->d_window_i16); (void)hipFree(h->d_dct_pack); (void)hipFree(h->d_dct_pack32); (void)hipFree(h->d_dct_rowsum); (void)hipFree(h->d_dct_pack16); (void)hipFree(h->d_dct_rowsum16); (void)hipFree(h->d_rich_tab);
     (void)hipFree(h->d_chroma_pack);
     (void)hipFree(h->d_window64); (void)hipFree(h->d_window64_i16); (void)hipFree(h->d_stage_tw64); (void)hipFree(h->d_post_tw64);
     h->ws_S.release(); h->ws_stat.release(); h->ws_flat.release(); h->ws_energy.release(); h->ws_hf.release(); h->ws_rowmax.release();
@@ -446,6 +474,8 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.window = h->d_window; a.window_i16 = h->d_window_i16; a.stage_tw = h->d_stage_tw; a.post_tw = h->d_post_tw;
   a.dct_pack = h->d_dct_pack; a.dct_rb = t.dct_pack.row_blocks; a.dct_groups = t.dct_groups;
   a.dct_pack32 = h->dct64 ? nullptr : h->d_dct_pack32; a.dct_rowsum = h->d_dct_rowsum; a.inv_n_mels = 1.0f / (float)p.n_mels;
+  // throughput presets: the DCT on the float16 MFMA (hi / lo split); the parity presets keep their float64 / float32 forms
+  a.dct_pack16 = (h->dct16 && !h->dct64 && !p.parity) ? (const void*)h->d_dct_pack16 : nullptr; a.dct_rowsum16 = h->d_dct_rowsum16;
   a.chroma_pack = h->d_chroma_pack; a.chroma_groups = t.chroma_groups;
   a.pip_kmin = t.pip_kmin; a.pip_kmax = t.pip_kmax;
   a.cand_cap = std::max(4096, 16 * ((t.pip_kmax - t.pip_kmin) / 2 + 2));   // 64 KB of LDS, or one round (16 frames) if that is more

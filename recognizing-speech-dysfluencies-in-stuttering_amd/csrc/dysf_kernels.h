@@ -47,6 +47,9 @@ struct KArgs {
   const double* dct_pack;  // float64 A operands
   const float* dct_pack32;   // float32 A operands of the same layout (null: run the DCT on the float64 MFMA)
   const double* dct_rowsum;  // [16*dct_rb] float64 sums of the float32 coefficients of every row
+  const void* dct_pack16;    // float16 hi / lo split of the same coefficients for v_mfma_f32_16x16x32_f16 (n_mels % 32 == 0):
+                             // [row block][K block of 32 mels][hi, lo * 2^11][64 lanes][8 halfs]; null: float32 MFMA
+  const double* dct_rowsum16;  // [16*dct_rb] float64 row sums of hi + lo * 2^-11 (the coefficients the split form multiplies by)
   float inv_n_mels;
   int dct_rb, dct_groups;  // row blocks of 16 coefficients, K groups of 16 mels
   const float* chroma_pack;

@@ -1159,8 +1159,14 @@ constexpr int kBDct = 144;     // float offset of the float64 DCT operands (8-by
 
 // RB = 1..3 fixes the geometry at compile time (n_mels == 16 * NG, dct_rb == RB: no mel masks, no per-block branches,
 // constant LDS offsets); RB = 0 reads it from the arguments.
-template <int NT, int NG, bool F32, int RB>
+// H16 (throughput presets, n_mels a multiple of 32): the DCT as three float16 MFMA products of a hi / lo split -- coefficients
+// D = Dh + Dl 2^-11 (host), mean-free log-mel x' = xh + xl -- Dh xh + Dh xl + 2^-11 Dl xh on v_mfma_f32_16x16x32_f16: float32
+// accumulation, operands carried to ~2^-22, 18 matrix instructions of 8 passes per 16-frame tile instead of 48 of 16 passes.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef __fp16 h2v __attribute__((ext_vector_type(2)));   // (the type __builtin_amdgcn_cvt_pkrtz returns)
+template <int NT, int NG, bool F32, int RB, bool H16 = false>
 __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
+  static_assert(!H16 || (F32 && RB > 0 && NG % 2 == 0), "the float16-split DCT needs whole 32-mel K blocks and a fixed geometry");
   constexpr int NW = NT / 64;
   constexpr int COLS = 16 * NW;
   constexpr int CH = COLS - 16;
@@ -1217,8 +1223,9 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   const double* rowsum = (const double*)(lds + kBDct + nd);
   float* chunk = lds + kBDct + (F32 ? nd + 2 * 16 * rbs : 2 * nd);
   if (F32) {
-    for (int i = tid * 4; i < nd; i += NT * 4) *(float4*)(lds + kBDct + i) = *(const float4*)(a.dct_pack32 + i);
-    for (int i = tid; i < 16 * rbs; i += NT) ((double*)(lds + kBDct + nd))[i] = a.dct_rowsum[i];
+    const float* psrc = H16 ? (const float*)a.dct_pack16 : a.dct_pack32;   // (the two packs have the same size)
+    for (int i = tid * 4; i < nd; i += NT * 4) *(float4*)(lds + kBDct + i) = *(const float4*)(psrc + i);
+    for (int i = tid; i < 16 * rbs; i += NT) ((double*)(lds + kBDct + nd))[i] = (H16 ? a.dct_rowsum16 : a.dct_rowsum)[i];
   } else {
     for (int i = tid * 2; i < nd; i += NT * 2) *(double2*)(dct + i) = *(const double2*)(a.dct_pack + i);
   }
@@ -1238,6 +1245,12 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
   auto fetch = [&](int t0n) {
     int t = t0n - 8 + wave * 16 + (lane & 15);
     t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    if (H16) {   // float16 MFMA operand order: lane (frame = l & 15, kb = l >> 4) holds mels 32 blk + 8 kb + {0..7}
+      const float* lrow = lm + (size_t)t * a.lm_stride + 8 * (lane >> 4);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) pf[g] = *(const float4*)(lrow + 32 * (g >> 1) + 4 * (g & 1));
+      return;
+    }
     const float* lrow = lm + (size_t)t * a.lm_stride + 4 * (lane >> 4);  // this lane's four mels of every 16-mel group
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -1254,6 +1267,52 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     // (only in a clip's last chunk; wave-uniform)
     const bool tile_live = t0 - 8 + wave * 16 <= T - 1;
     if (!tile_live) {
+    } else if constexpr (H16) {
+      float4 xq[NG];
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        xq[g].x = fmaxf(pf[g].x, floor_db); xq[g].y = fmaxf(pf[g].y, floor_db);
+        xq[g].z = fmaxf(pf[g].z, floor_db); xq[g].w = fmaxf(pf[g].w, floor_db);
+        sum += (xq[g].x + xq[g].y) + (xq[g].z + xq[g].w);
+      }
+      fetch(t0 + CH);
+      sum += __shfl_xor(sum, 16);  // the four lanes of a frame (lane & 15) end up with the same total
+      sum += __shfl_xor(sum, 32);
+      const float m32 = sum * a.inv_n_mels;
+      h8v bh[NG / 2], bl[NG / 2];   // x' = xh + xl per K block of 32 mels
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float x0 = xq[g].x - m32, x1 = xq[g].y - m32, x2 = xq[g].z - m32, x3 = xq[g].w - m32;
+        const h2v h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+        const h2v l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
+        const h2v l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+        const int o = 4 * (g & 1);
+        bh[g >> 1][o] = (_Float16)h01[0]; bh[g >> 1][o + 1] = (_Float16)h01[1]; bh[g >> 1][o + 2] = (_Float16)h23[0]; bh[g >> 1][o + 3] = (_Float16)h23[1];
+        bl[g >> 1][o] = (_Float16)l01[0]; bl[g >> 1][o + 1] = (_Float16)l01[1]; bl[g >> 1][o + 2] = (_Float16)l23[0]; bl[g >> 1][o + 3] = (_Float16)l23[1];
+      }
+      const h8v* dp = (const h8v*)(lds + kBDct) + lane;   // [row block][K block][hi, lo][lane]
+      f32x4 acc0[RB], acc1[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) { acc0[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int b = 0; b < NG / 2; ++b)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const h8v ah = dp[((rb * (NG / 2) + b) * 2 + 0) * 64], al = dp[((rb * (NG / 2) + b) * 2 + 1) * 64];
+          acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b], acc0[rb], 0, 0, 0);
+          acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b], acc1[rb], 0, 0, 0);
+          acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b], acc0[rb], 0, 0, 0);
+        }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // f32 C/D map: row = 4 * (lane >> 4) + reg, col = lane & 15
+          const int row = rb * 16 + 4 * (lane >> 4) + r;
+          const int ib = 4 * (lane >> 4) + r;
+          chunk[((rb * 8 + (ib & 7)) * CSTR + wave * 16 + (lane & 15)) * 2 + (ib >> 3)] =
+              (float)((double)fmaf(acc1[rb][r], 1.0f / 2048.0f, acc0[rb][r]) + (double)m32 * rowsum[row]);
+        }
     } else if constexpr (F32) {
       // float32 MFMA on mean-free columns: with x' = x - m (m = any per-frame constant near the column mean)
       // D x = D x' + m * rowsum(D) exactly, the sums the MFMA carries stay small (silent / clamped frames give
@@ -2093,6 +2152,7 @@ hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t 
   // 128-mel presets stay on the float64 MFMA (same results to ~1e-5, see tests/diagnostics/margin.py).
   const int full = (a.n_mels == 16 * a.dct_groups) ? a.dct_groups : 0;   // every 16-mel group complete: a fixed-geometry build may apply
   if (a.dct_pack32 && a.dct_groups <= 4) {
+    if (full == 4 && a.dct_rb == 3 && a.dct_pack16) return launch_one(dysf_mfcc_kernel<512, 4, true, 3, true>, grid, 512, lds_bytes, s, a);
     if (full == 4 && a.dct_rb == 3) return launch_one(dysf_mfcc_kernel<512, 4, true, 3>, grid, 512, lds_bytes, s, a);
     if (full == 4 && a.dct_rb == 1) return launch_one(dysf_mfcc_kernel<512, 4, true, 1>, grid, 512, lds_bytes, s, a);
     return launch_one(dysf_mfcc_kernel<512, 4, true, 0>, grid, 512, lds_bytes, s, a);

@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/r02/ (written on the GPU box by tools/collect_r02.sh) into the committed profile artefacts:
-profiles/r02_*_kernel_stats.csv, profiles/r02_pmc_*.txt (per-kernel per-launch counter averages) and
-profiles/r02_counters.json (derived figures that bench.py quotes, stamped with the id of the kernel sources)."""
+"""Turns gpurun_out/rNN/ (written on the GPU box by tools/collect_rNN.sh) into the committed profile artefacts:
+profiles/rNN_*_kernel_stats.csv, profiles/rNN_pmc_*.txt (per-kernel per-launch counter averages) and
+profiles/rNN_counters.json (derived figures that bench.py quotes, stamped with the id of the kernel sources).
+  python tools/make_counters_json.py [r03]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # kernel_source_id()
-SRC, DST = os.path.join(ROOT, "gpurun_out", "r02"), os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC, DST = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
 def read_pmc(name):
     out = {}
-    for f in glob.glob(os.path.join(SRC, f"r02_pmc_{name}_*.txt")):
+    for f in glob.glob(os.path.join(SRC, f"{TAG}_pmc_{name}_*.txt")):
         shutil.copy(f, DST)
         for line in open(f):
             k, c, v, n = line.rstrip("\n").split("\t")
@@ -21,7 +23,7 @@ def read_pmc(name):
 
 
 def durations(name):
-    f = os.path.join(SRC, f"r02_{name}_kernel_stats.csv")
+    f = os.path.join(SRC, f"{TAG}_{name}_kernel_stats.csv")
     shutil.copy(f, DST)
     d = {}
     for r in csv.DictReader(open(f)):
@@ -65,16 +67,17 @@ def derive(c, us):
 
 def limited(r):
     s = r.get("wave_time_split", {})
-    return ("not HBM: VALU %.0f %% busy, LDS %.0f %%, MFMA %.0f %%; waves spend %.0f %% of their time parked at s_waitcnt / barriers and %.0f %% "
-            "issue-stalled -- dependent latency (LDS round trips of the FFT, MFMA chains) at the occupancy the registers allow"
+    return ("not HBM: instruction issue -- VALU %.0f %% busy (4-cycle accounting), LDS %.0f %%, MFMA %.0f %%; waves spend %.0f %% of their time parked at "
+            "s_waitcnt and %.0f %% issue-stalled; every instruction of any kind costs the SIMD ~3-6 issue cycles at this occupancy "
+            "(tools/ubench/valu_rate.hip), so the floor is the instruction count"
             % (100 * r.get("valu_busy", 0), 100 * r.get("lds_busy", 0), 100 * r.get("mfma_busy", 0),
                100 * s.get("parked_at_waitcnt_or_barrier", 0), 100 * s.get("issue_stalled", 0)))
 
 
-out = {"round": 2, "kernel_source_id": bench.kernel_source_id(),
-       "how": "tools/collect_r02.sh on one MI355X: rocprofv3 --kernel-trace --stats, and separate rocprofv3 --kernel-trace --pmc passes "
+out = {"round": int(TAG[1:]), "kernel_source_id": bench.kernel_source_id(),
+       "how": "tools/collect_" + TAG + ".sh on one MI355X: rocprofv3 --kernel-trace --stats, and separate rocprofv3 --kernel-trace --pmc passes "
               "(SQ counters in groups of 8, FETCH_SIZE and WRITE_SIZE each alone) of `python bench.py --lanes 1 --no-cpu-baseline "
-              "--no-host-rate --bank-workers 1 [--preset reference_149 | --head cnn]`; per-launch averages in profiles/r02_pmc_*.txt"}
+              "--no-host-rate --bank-workers 1 [--preset reference_149 | --head cnn]`; per-launch averages in profiles/" + TAG + "_pmc_*.txt"}
 for name in ("bench", "reference_149", "cnn"):
     pm, du = read_pmc(name), durations(name)
     kern = {}
@@ -83,8 +86,8 @@ for name in ("bench", "reference_149", "cnn"):
             continue
         kern[k] = derive(c, du.get(k, 0.0))
     feat = [k for k in kern if k.startswith(("dysf_stft", "dysf_mfcc", "dysf_chroma"))]
-    dom = "dysf_stft_mel_kernel" if name != "cnn" else next((k for k in kern if "conv2" in k), None)
-    entry = {"kernel_source_id": out["kernel_source_id"], "source": f"profiles/r02_pmc_{name}_*.txt, profiles/r02_{name}_kernel_stats.csv",
+    dom = next((k for k in kern if k.startswith("dysf_stft")), None) if name != "cnn" else next((k for k in kern if "conv2" in k), None)
+    entry = {"kernel_source_id": out["kernel_source_id"], "source": f"profiles/{TAG}_pmc_{name}_*.txt, profiles/{TAG}_{name}_kernel_stats.csv",
              "kernels": kern}
     if all("hbm_read_bytes" in kern[k] for k in feat) and feat:
         entry["hbm_bytes_per_launch"] = sum(kern[k]["hbm_read_bytes"] + kern[k]["hbm_write_bytes"] for k in feat)
@@ -94,10 +97,10 @@ for name in ("bench", "reference_149", "cnn"):
         entry["valu_busy"], entry["mfma_busy"] = kern[dom].get("valu_busy"), kern[dom].get("mfma_busy")
         entry["limited_by"] = limited(kern[dom])
     out["bench_512" if name == "bench" else name] = entry
-json.dump(out, open(os.path.join(DST, "r02_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(DST, TAG + "_counters.json"), "w"), indent=1)
 for name in ("bench", "reference_149", "cnn"):
     f = os.path.join(SRC, f"trace_{name}.json")
     if os.path.exists(f):
-        shutil.copy(f, os.path.join(DST, f"r02_{name}_bench_under_rocprof.json"))
+        shutil.copy(f, os.path.join(DST, f"{TAG}_{name}_bench_under_rocprof.json"))
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} if isinstance(v, dict) else v for k, v in out.items()}, indent=1))
 print(json.dumps(out["bench_512"]["kernels"], indent=1))
