@@ -19,6 +19,7 @@
 // Clips of different lengths share one launch: cols[clip] valid columns per clip (BASELINE configs[4]), everything
 // past them -- conv padding, pooling, the global average -- behaves as if the clip had been run alone.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
@@ -320,7 +321,6 @@ struct DysfCnn {
   void* act1 = nullptr; size_t act1_clips = 0;
   void* sums = nullptr; size_t sums_clips = 0;
   int act_h = 0, act_w = 0;  // geometry the workspace was laid out for
-  size_t lds_granted[3] = {0, 0, 0};  // dynamic-LDS attribute already raised per conv2 kernel
   int precision = DYSF_CNN_F16;
   bool fused = true;  // DYSF_CNN_SPLIT=1: conv1 as its own kernel with the activations in HBM (float16 handles only)
 };
@@ -333,6 +333,23 @@ static bool up(DysfCnn* m, const T** dst, const std::vector<T>& src) {
   m->bufs.push_back(p);
   if (hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
   *dst = (const T*)p;
+  return true;
+}
+
+// The dynamic-LDS attribute belongs to the kernel function (per device), not to a handle: one process-wide table keyed by
+// function and device, only ever raised (handles on different streams see different batch widths).
+static bool grant_dynamic_lds(const void* kern, size_t lds_bytes) {
+  struct Entry { const void* fn; int dev; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> table;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (Entry& x : table) if (x.fn == kern && x.dev == dev) { e = &x; break; }
+  if (e && lds_bytes <= e->bytes) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
+  if (e) e->bytes = lds_bytes; else table.push_back({kern, dev, lds_bytes});
   return true;
 }
 
@@ -435,14 +452,10 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   if (lds > 160 * 1024) { g_cerr = "feature map too wide for the LDS tile"; return DYSF_E_INVALID; }
   size_t lds_launch = lds;
   if (const char* e = std::getenv("DYSF_CNN_LDS")) lds_launch = std::max(lds, (size_t)std::atoll(e));   // co-residency experiments
-  const int which = f32 ? 2 : (m->fused ? 0 : 1);
-  if (lds_launch > m->lds_granted[which]) {  // raised once per kernel, and again only when a wider batch needs more
+  {
     const void* fn = f32 ? (const void*)dysf_cnn_conv2_f32_kernel
                          : (m->fused ? (const void*)dysf_cnn_conv2_kernel<true> : (const void*)dysf_cnn_conv2_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch) != hipSuccess) {
-      g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP;
-    }
-    m->lds_granted[which] = lds_launch;
+    if (!grant_dynamic_lds(fn, lds_launch)) { g_cerr = "hipFuncSetAttribute failed"; return DYSF_E_HIP; }
   }
   const dim3 grid2(d.n_tiles, n);
   if (f32) {

@@ -13,6 +13,7 @@
 // pack in LDS was measured too: equal at 1024 rows, twice as slow at 16 384 (one workgroup per CU).
 // float32 accumulation in a fixed order: results do not depend on the batch.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -146,7 +147,6 @@ __global__ __launch_bounds__(kThreads) void dysf_mlp_kernel(MlpDev m, const floa
 struct DysfMlp {
   int device = 0;
   int blocks_per_wave = 1;   // of the widest layer: ceil(ceil(dout / 16) / 4)
-  bool attr_set = false;
   MlpDev d{};
   std::vector<void*> bufs;
 };
@@ -159,6 +159,23 @@ static bool up(DysfMlp* m, const T** dst, const std::vector<T>& src) {
   m->bufs.push_back(p);
   if (hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
   *dst = (const T*)p;
+  return true;
+}
+
+// The dynamic-LDS attribute belongs to the kernel function (per device), not to a handle: one process-wide table keyed by
+// function and device, only ever raised (handles on different streams see different batch widths).
+static bool grant_dynamic_lds(const void* kern, size_t lds_bytes) {
+  struct Entry { const void* fn; int dev; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> table;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (Entry& x : table) if (x.fn == kern && x.dev == dev) { e = &x; break; }
+  if (e && lds_bytes <= e->bytes) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
+  if (e) e->bytes = lds_bytes; else table.push_back({kern, dev, lds_bytes});
   return true;
 }
 
@@ -227,10 +244,7 @@ int32_t dysf_mlp_forward_dev(DysfMlp* m, const float* d_x, int32_t n, float* d_l
   if (hipSetDevice(m->device) != hipSuccess) { g_merr = "hipSetDevice failed"; return DYSF_E_HIP; }
   const size_t lds = (size_t)2 * kRows * m->d.width * sizeof(float);   // <= 66 KB
   auto launch = [&](auto kernel) -> bool {
-    if (!m->attr_set && lds > 64 * 1024) {  // more than the default 64 KB of dynamic LDS
-      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-      m->attr_set = true;
-    }
+    if (lds > 64 * 1024 && !grant_dynamic_lds((const void*)kernel, lds)) return false;  // more than the default 64 KB of dynamic LDS
     hipLaunchKernelGGL(kernel, dim3((n + kRows - 1) / kRows), dim3(kThreads), lds, (hipStream_t)stream, m->d, d_x, n, d_logits,
                        d_proba, d_pred);
     return true;
