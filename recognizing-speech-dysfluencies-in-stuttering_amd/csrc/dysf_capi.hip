@@ -62,6 +62,7 @@ struct DysfHandle {
   // workspace / staging
   DevBuf ws_rich, ws_S, ws_stat, ws_flat, ws_energy, ws_hf, ws_rowmax;
   DevBuf ws_logmel, ws_peak_mag, ws_peak_bin, ws_small;
+  DevBuf ws_cand, ws_framecnt;   // kernel A-exact -> kernel C: per-frame lists of piptrack's local maxima
   size_t ws_budget = (size_t)4 << 30;  // bytes of per-clip workspace before a batch is split (DYSF_WS_MB overrides)
   bool sched_built = false;
   int64_t last_sub = 0, last_peak_stride = 0;  // geometry of the most recent launch (dysf_debug_peaks)
@@ -76,6 +77,7 @@ struct DysfHandle {
   // kernel A2 (wave-private STFT + mel): block schedule of the 4x4x1 mel product
   DevBuf d_mel4_pack, d_mel4_kbeg;
   int mel4_steps = 0, mel4_rounds = 0;
+  int exact_variant = 0; // DYSF_EXACT: 1 keeps kernel A for the parity presets at n_fft 2048 (A/B checks), else kernel A-exact
   int stft_variant = 0;  // DYSF_STFT: 0 choose (A2 where it applies), 1 always kernel A, 2 same as 0
 };
 
@@ -120,6 +122,7 @@ int32_t dysf_create(const DysfParams* p, int32_t device, DysfHandle** out) {
   if (const char* e = std::getenv("DYSF_DCT16")) h->dct16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DYSF_WS_MB")) { if (std::atoll(e) > 0) h->ws_budget = (size_t)std::atoll(e) << 20; }
   if (const char* e = std::getenv("DYSF_STFT")) h->stft_variant = std::atoi(e);
+  if (const char* e = std::getenv("DYSF_EXACT")) h->exact_variant = std::atoi(e);
   if (device >= 0) {
     int rc = 0;
     hipError_t e = hipSetDevice(device);
@@ -189,6 +192,7 @@ void dysf_destroy(DysfHandle* h) {
     (void)hipFree(h->d_window64); (void)hipFree(h->d_window64_i16); (void)hipFree(h->d_stage_tw64); (void)hipFree(h->d_post_tw64);
     h->ws_S.release(); h->ws_stat.release(); h->ws_flat.release(); h->ws_energy.release(); h->ws_hf.release(); h->ws_rowmax.release();
     h->ws_rich.release(); h->ws_logmel.release(); h->ws_peak_mag.release(); h->ws_peak_bin.release(); h->ws_small.release();
+    h->ws_cand.release(); h->ws_framecnt.release();
     h->st_pcm.release(); h->st_off.release(); h->st_pooled.release(); h->st_frames.release();
     h->st_status.release(); h->st_tuning.release(); h->d_mel_sched.release(); h->d_mel_spack.release();
     h->d_mel4_pack.release(); h->d_mel4_kbeg.release();
@@ -516,6 +520,15 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   if (const char* e = std::getenv("DYSF_LDS_PAD")) lds_a += (size_t)std::atoi(e);  // occupancy experiments only
   if (lds_a > h->lds_limit) return fail(DYSF_E_INVALID, "hop too large for the LDS tile");
 
+  // ---- kernel A-exact: the parity presets at n_fft 2048 (the reference's parameterisation), two workgroups per CU
+  const bool use_ex = p.parity && p.n_fft == 2048 && h->exact_variant != 1;
+  const int lds_ex_misc = nw_a * kExRegion, lds_ex_tables = lds_ex_misc + misc_a;
+  const size_t lds_ex = (size_t)(lds_ex_tables + stft_exact2048_table_floats()) * 4;
+  if (use_ex) {
+    if (lds_ex > h->lds_limit) return fail(DYSF_E_INVALID, "mel schedule too large for the LDS of the 2048-point parity kernel");
+    if (const char* e = std::getenv("DYSF_TILES")) { if (std::atoi(e) > 0) a.tiles_per_wg = std::atoi(e); } else a.tiles_per_wg = 4;
+  }
+
   // ---- kernel A2 (wave-private STFT + mel): the throughput presets at n_fft 512
   const bool use_a2 = h->stft_variant != 1 && p.n_fft == 512 && !p.parity && !p.chroma && !dbg_S && !d_metrics &&
                       p.hop <= 4096;
@@ -585,7 +598,10 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int snr_fl = (int)(0.025 * p.sr), snr_hop = (int)(0.010 * p.sr);
   const long long hf_M = d_metrics ? hf_ratio_fft_size(max_samples) : 0;
   a.energy_stride = d_metrics ? std::max<int64_t>(1, max_samples >= snr_fl ? 1 + (max_samples - snr_fl) / std::max(1, snr_hop) : 1) : 0;
-  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (size_t)a.ws_rich_stride * 14 * 4 +
+  // kernel A-exact picks piptrack's local maxima from the rows in LDS (kernel C then keeps one prefix sum per frame in LDS)
+  const bool ex_picks = use_ex && p.chroma && (size_t)(t_max + 2) * 4 + 4096 <= h->lds_limit;
+  a.cand_per_frame = (t.pip_kmax - t.pip_kmin) / 2 + 2;
+  const size_t per_clip = (size_t)a.ws_logmel_stride * 4 + 16 + (size_t)a.ws_peak_stride * 8 + (ex_picks ? (size_t)a.ws_peak_stride * 16 + (size_t)t_max * 4 : 0) + (size_t)a.ws_rich_stride * 14 * 4 +
                           (size_t)a.ws_S_stride * 4 + (p.chroma ? (size_t)t_max * 4 : 0) + (size_t)a.stat_stride * 3 * p.n_mfcc * 4 +
                           (d_metrics ? (size_t)(t_max + a.energy_stride) * 4 + hf_ratio_bytes_per_clip(hf_M) : 0);
   // a sub-batch is gridDim.y of kernel A: at most 65535 clips
@@ -597,6 +613,12 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     if (int rc = h->ws_peak_mag.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
     if (int rc = h->ws_peak_bin.reserve((size_t)sub * a.ws_peak_stride * 4)) return rc;
   }
+  if (ex_picks) {
+    if (int rc = h->ws_cand.reserve((size_t)sub * a.ws_peak_stride * 16)) return rc;
+    if (int rc = h->ws_framecnt.reserve((size_t)sub * t_max * 4)) return rc;
+  }
+  a.ws_cand = ex_picks ? (float4*)h->ws_cand.p : nullptr;
+  a.ws_framecnt = (int*)h->ws_framecnt.p;
   if (p.rich) { if (int rc = h->ws_rich.reserve((size_t)sub * a.ws_rich_stride * 14 * 4)) return rc; }
   if (p.chroma) {
     if (int rc = h->ws_S.reserve((size_t)sub * a.ws_S_stride * 4)) return rc;
@@ -621,7 +643,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   const int groups = (tiles_max + a.tiles_per_wg - 1) / a.tiles_per_wg;
   if (std::getenv("DYSF_VERBOSE"))
     std::fprintf(stderr, "[dysf] stft: %d thr, grid %dx%lld, lds %zu B | mfcc: lds %zu B | rich: lds %zu B | sub-batch %lld clips, slots %d\n",
-                 nt_a, groups, (long long)sub, lds_a, lds_b, p.rich ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
+                 nt_a, groups, (long long)sub, use_ex ? lds_ex : lds_a, lds_b, p.rich ? lds_c : (size_t)0, (long long)sub, h->mel_slots);
 
   h->last_sub = sub; h->last_peak_stride = a.ws_peak_stride;
   for (int64_t c0 = 0; c0 < n_clips; c0 += sub) {
@@ -643,7 +665,10 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
     a.rstride = rstride;
     a.lds_region = lds_a_region; a.lds_pcm = lds_a_pcm; a.lds_misc = lds_a_misc; a.lds_tables = lds_a_tables;
     if (h->timing) HIPCHK(hipEventRecord(h->tev[0], stream));
-    if (use_a2) {
+    if (use_ex) {
+      a.rstride = kExRegion; a.lds_region = 0; a.lds_pcm = 0; a.lds_misc = lds_ex_misc; a.lds_tables = lds_ex_tables;
+      HIPCHK(launch_stft_mel_exact2048(a, pcm_type, dim3(groups, nc), lds_ex, stream));
+    } else if (use_a2) {
       a.lds_region = 0; a.lds_tables = a2_nw * kA2Region; a.lds_misc = a2_nw * kA2Region + 16 * 84; a.lds_pcm = 0;
       HIPCHK(launch_stft_mel_wave(a, pcm_type, a2_nw, a2_occ, dim3(a2_groups, nc), lds_a2, stream));
     } else {

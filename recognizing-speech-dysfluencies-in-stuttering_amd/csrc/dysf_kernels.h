@@ -83,6 +83,11 @@ struct KArgs {
   float* ws_peak_mag;
   int* ws_peak_bin;
   long long ws_peak_stride;    // peak capacity per clip
+  float4* ws_cand;             // kernel A-exact -> kernel C: [clip][t_max][cand_per_frame] piptrack's local maxima (bin, power, left,
+                               // right neighbour) of every frame, picked from the spectrum row while it is in LDS; null: kernel C
+                               // picks them from the stored spectrogram itself (a second pass over it)
+  int* ws_framecnt;            // [clip][t_max] local maxima of every frame
+  int cand_per_frame;          // slots per frame = (pip_kmax - pip_kmin) / 2 + 2 (local maxima cannot be adjacent)
   // LDS carve-up (float offsets) of the kernel being launched
   int lds_region, lds_pcm, lds_misc, lds_tables;
   // kernel A2 (wave-private STFT + mel, throughput presets at n_fft 512): mel product on v_mfma_f32_4x4x1_16B_f32
@@ -114,6 +119,10 @@ constexpr int stft_threads(int nc) { return nc <= 256 ? 256 : 512; }
 
 hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_stft_mel_wave(const KArgs& a, int pcm_type, int waves_per_wg, int waves_per_simd, dim3 grid, size_t lds_bytes, hipStream_t s);  // kernel A2
+// kernel A-exact (parity presets at n_fft 2048): 512 threads, kExRegion floats of LDS per wave
+constexpr int kExRegion = 1096;
+int stft_exact2048_table_floats();
+hipError_t launch_stft_mel_exact2048(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_mfcc(const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s);
 hipError_t launch_metrics(const KArgs& a, dim3 grid, hipStream_t s);

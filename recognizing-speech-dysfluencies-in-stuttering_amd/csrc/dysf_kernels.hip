@@ -646,9 +646,24 @@ __device__ __forceinline__ void mel_epilogue(f32x4 acc, const MelSeg& g, const K
       stamp_last = now_;                                                      \
     }                                                                         \
   } while (0)
+struct Stamper {   // the same for code in device functions (kernel A-exact)
+  unsigned long long* slot;
+  unsigned long long last;
+  __device__ __forceinline__ void init(const KArgs& a) {
+    slot = (threadIdx.x == 0 && a.dbg_stamps) ? a.dbg_stamps + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 : nullptr;
+    last = __builtin_readcyclecounter();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (slot) { const unsigned long long now = __builtin_readcyclecounter(); slot[i] += now - last; last = now; }
+  }
+};
 #else
 #define STAMP_INIT do {} while (0)
 #define STAMP(i) do {} while (0)
+struct Stamper {
+  __device__ __forceinline__ void init(const KArgs&) {}
+  __device__ __forceinline__ void mark(int) {}
+};
 #endif
 
 // =============================================================================================
@@ -827,6 +842,412 @@ __global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_me
 }
 
 // =============================================================================================
+// Kernel A-exact: kernel A for the parity presets at n_fft 2048 -- the reference's own parameterisation
+// (librosa.feature.mfcc / chroma_stft defaults, pipeline1.py:216-228).  Same arithmetic as kernel A's float64 path (bit-equal
+// results), laid out so that TWO workgroups share a CU (kernel A's 140 KB of LDS allow one: 2 waves per SIMD):
+//   * no PCM tile: a wave owns one frame, and every lane loads its 16 complex points straight from global memory (the
+//     next tile's loads are issued before the mel phase and land during it);
+//   * the float64 exchange buffer is HALF a frame (512 doubles per wave): v_permlane32_swap first trades registers 0..7 of
+//     lanes 32..63 for registers 8..15 of lanes 0..31, after which registers 0..7 of ALL lanes hold the lower half of the
+//     stage's output and go through the buffer in one round, registers 8..15 in a second one;
+//   * the last transpose is not one: Z[k] already sits in register k / 64 of lane k % 64, and its un-packing partner
+//     Z[NC - k] comes from lane 64 - ls through ds_bpermute_b32 (no LDS memory);
+//   * stage-1 twiddles depend on ls % 16 only: 240 table entries instead of 960;
+//   * |X|^2 as NumPy computes it is evaluated branch-free on packed float32 pairs; a wave re-does a group of bins with the
+//     general sequence only when one of its bins lies outside the range the short sequence is exact for (silent frames);
+//   * chroma presets: piptrack's local maxima are picked here from the spectrum row in LDS (kernel C then reads the stored
+//     spectrogram once, for the chroma product, instead of twice).
+// 512 threads, a tile is 8 frames (one per wave); the mel product, its schedule and the epilogue are kernel A's.
+// kExRegion (dysf_kernels.h) floats of LDS per wave: 544 doubles of exchange buffer, later the 1025-bin spectrum row + zero
+// tail (% 32 == 8: the eight rows the mel product reads together start on different banks)
+constexpr int kExTabFloats = 4 * 1024 + 4 * 513 + 4 * 15 * 16 + 4 * 4 * 64;
+int stft_exact2048_table_floats() { return kExTabFloats; }
+struct ExTabs {
+  const cd* win;   // [1024] (w[2n], w[2n+1]) / 2 (times 2^-15 for int16 PCM)
+  const cd* ptw;   // [513] un-packing twiddles
+  const cd* t1;    // [15][16] stage-1 twiddles of point p = q + 1, lane ls % 16
+  const cd* t2;    // [4][64] stage-2 base twiddles (r = 1) of butterfly b, lane ls
+};
+// 4-byte-per-lane loads of sample pairs; a clip may start at an odd sample of the flat buffer (2-byte alignment)
+typedef int i32_a2 __attribute__((aligned(2)));
+typedef int i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+template <int PCM>
+struct FramePcm { int v[PCM == DYSF_PCM_I16 ? 16 : 32]; };
+
+// this lane's 16 complex points (32 samples) of the frame that starts at sample s_t of the clip; zeros outside [0, n)
+template <int PCM>
+__device__ __forceinline__ void frame_prefetch(FramePcm<PCM>& st, const char* pbase, int n, bool live, int s_t, int ls) {
+  constexpr int NC = 1024;
+  if (live && s_t >= 0 && s_t + 2 * NC <= n) {   // wave-uniform: the frame lies inside the clip
+    if (PCM == DYSF_PCM_I16) {
+      const char* p0 = pbase + 2 * (s_t + 2 * ls);
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) st.v[p] = *(const i32_a2*)(p0 + 256 * p);
+    } else {
+      const char* p0 = pbase + 4 * (s_t + 2 * ls);
+#pragma unroll
+      for (int p = 0; p < kPts; ++p) {
+        const i32x2_a4 w = *(const i32x2_a4*)(p0 + 512 * p);
+        st.v[2 * p] = w[0]; st.v[2 * p + 1] = w[1];
+      }
+    }
+    return;
+  }
+  // edge frames: clamped (always valid) loads, zeroed afterwards where the position lies outside the clip
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    const int i0 = s_t + 2 * (ls + 64 * p);
+    const bool in0 = live && i0 >= 0 && i0 < n, in1 = live && i0 + 1 >= 0 && i0 + 1 < n;
+    const int c0 = min(max(i0, 0), n - 1), c1 = min(max(i0 + 1, 0), n - 1);
+    if (PCM == DYSF_PCM_I16) {
+      const unsigned short* b = (const unsigned short*)pbase;
+      const unsigned lo = b[c0], hi = b[c1];
+      st.v[p] = (int)((in0 ? lo : 0u) | ((in1 ? hi : 0u) << 16));
+    } else {
+      const int* b = (const int*)pbase;
+      const int lo = b[c0], hi = b[c1];
+      st.v[2 * p] = in0 ? lo : 0;
+      st.v[2 * p + 1] = in1 ? hi : 0;
+    }
+  }
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// lanes 32..63 of a <-> lanes 0..31 of b (v_permlane32_swap_b32 on both halves of the doubles)
+__device__ __forceinline__ void swap_lane_halves(double& a, double& b) {
+  const u32x2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u32x2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// Transpose after stage SPREV (0 or 1) through the half-size buffer.  After the swap register p' < 8 of lane l holds the
+// stage's output (source lane l & 31, point p' + 8 (l >> 5)), register p' + 8 the output (source lane 32 + (l & 31), same
+// point): output indices below / from NC/2 -- exactly what registers 0..7 / 8..15 of all lanes read back.
+template <int SPREV>
+__device__ __forceinline__ void ex_exchange(cd* z, double* xb, int lane) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double lo = z[p][h], hi = z[p + 8][h];
+      swap_lane_halves(lo, hi);
+      z[p][h] = lo; z[p + 8][h] = hi;
+    }
+  }
+  const int sl = lane & 31, pe = 8 * (lane >> 5);
+  // padded (pad_idx) position of the lane's first value and the step between its registers
+  const int wb = SPREV == 0 ? 17 * sl + pe : (sl >> 4) * 272 + (sl & 15) + 17 * pe;
+  constexpr int ws = SPREV == 0 ? 1 : 17;
+  const int rb = lane + (lane >> 4);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) xb[wb + ws * p] = z[p + 8 * rnd][h];
+      wave_lds_sync();
+#pragma unroll
+      for (int p = 0; p < 8; ++p) z[p + 8 * rnd][h] = xb[rb + 68 * p];
+      wave_lds_sync();
+    }
+  }
+}
+
+// np.abs(complex64)**2 of two values at once (the pair of bins a lane un-packs together), NumPy's rounding sequence of
+// cabs2_numpy on packed float32; *slow is set when a magnitude lies outside the range div_rn_unit is exact for.
+__device__ __forceinline__ cf cabs2_numpy_pair(cf re, cf im, bool* slow) {
+#pragma clang fp contract(off)
+  const cf ar = __builtin_elementwise_abs(re), ai = __builtin_elementwise_abs(im);
+  const cf lg = __builtin_elementwise_max(ar, ai), sm = __builtin_elementwise_min(ai, ar);
+  *slow = *slow || !(fminf(lg[0], lg[1]) > 8.7e-19f && fmaxf(lg[0], lg[1]) < 1.1e18f);
+  const cf one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+  cf r = {__builtin_amdgcn_rcpf(lg[0]), __builtin_amdgcn_rcpf(lg[1])};
+  const cf e = __builtin_elementwise_fma(-lg, r, one);
+  r = __builtin_elementwise_fma(e, r, r);
+  const cf q = sm * r;
+  const cf rem = __builtin_elementwise_fma(-lg, q, sm);
+  const cf ratio = __builtin_elementwise_fma(rem, r, q);
+  const cf t = __builtin_elementwise_fma(ratio, ratio, one);
+  const cf s = {__builtin_amdgcn_rsqf(t[0]), __builtin_amdgcn_rsqf(t[1])};
+  cf g = t * s, hh = half * s;
+  const cf rr = __builtin_elementwise_fma(-hh, g, half);
+  g = __builtin_elementwise_fma(g, rr, g);
+  hh = __builtin_elementwise_fma(hh, rr, hh);
+  const cf d = __builtin_elementwise_fma(-g, g, t);
+  const cf sq = __builtin_elementwise_fma(d, hh, g);
+  const cf m = sq * lg;
+  return m * m;
+}
+
+// librosa.piptrack's candidate bins of one frame, taken from its spectrum row in LDS: local maxima (x[k] > x[k-1],
+// x[k] >= x[k+1]) above 0.1 * the frame's largest bin inside [kmin, kmax) -- the same decision kernel C makes on the
+// thresholded values (for x0 > ref >= 0 the thresholding of the neighbours cannot change either comparison).  They go to the
+// frame's own slots of the workspace (bin, power, neighbours; positions from ballot pop-counts), the count next to them;
+// kernel C turns them into (interpolated magnitude, histogram bin) densely.
+__device__ __forceinline__ void ex_pick_peaks(const float* srow, float mx, int lane, float4* cand, int* count, int kmin, int kmax) {
+  const float ref = mul_rn(0.1f, mx);
+  int cnt = 0;   // wave-uniform
+  const int nsl = (kmax + 255) >> 8;   // 256-bin slices that hold candidate bins
+  for (int i = 0; i < nsl; ++i) {
+    const float* row = srow + 256 * i + 4 * lane;   // (the row's zero tail follows bin 1024)
+    const float4 c = *(const float4*)row;
+    const float left = row[(i == 0 && lane == 0) ? 0 : -1];   // bin 0 has no left neighbour: never a local maximum
+    const float right = row[4];
+    const float xs[6] = {left, c.x, c.y, c.z, c.w, right};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 256 * i + 4 * lane + j;
+      const float x0 = xs[j + 1], xm = xs[j], x1 = xs[j + 2];
+      const bool is_peak = (k >= kmin) && (k < kmax) && (x0 > ref) && (x0 > xm) && (x0 >= x1);
+      const unsigned long long mask = __ballot(is_peak);
+      const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+      if (is_peak) cand[cnt + below] = make_float4(__int_as_float(k), x0, xm, x1);
+      cnt += __popcll(mask);
+    }
+  }
+  if (lane == 0) *count = cnt;
+}
+
+constexpr int EXG = 1;   // bin pairs un-packed together (9 % EXG == 0): more overlap the reciprocal / square-root chains, fewer fit 128 registers
+// One frame: staged samples -> window -> float64 FFT -> complex64 -> |.|^2 row in srow (and in the workspace row grow);
+// returns the frame's largest bin in every lane.
+template <int PCM>
+__device__ __forceinline__ float ex_frame_power(const FramePcm<PCM>& st, double* xb, float* srow, int lane, const ExTabs& tb,
+                                                float* grow, int s_stride, bool* bad, Stamper& sp) {
+  constexpr int NC = 1024;
+  cd z[kPts];
+#pragma unroll
+  for (int p = 0; p < kPts; ++p) {
+    cd x;
+    if (PCM == DYSF_PCM_I16) {
+      x[0] = (double)(short)(st.v[p] & 0xffff); x[1] = (double)(st.v[p] >> 16);
+    } else {
+      const float f0 = __int_as_float(st.v[2 * p]), f1 = __int_as_float(st.v[2 * p + 1]);
+      *bad = *bad || !(isfinite(f0) && isfinite(f1));
+      x[0] = (double)f0; x[1] = (double)f1;
+    }
+    z[p] = x * (tb.win + lane)[64 * p];   // one float64 rounding per sample, as numpy's float64(frame) * window
+  }
+  fft_butterflies<NC, 0>(z);
+  sp.mark(1);   // convert + window + stage 0
+  ex_exchange<0>(z, xb, lane);
+  sp.mark(2);   // exchange
+#pragma unroll
+  for (int p = 1; p < kPts; ++p) z[p] = cmul(z[p], tb.t1[(p - 1) * 16 + (lane & 15)]);
+  fft_butterflies<NC, 1>(z);
+  sp.mark(3);   // stage 1
+  ex_exchange<1>(z, xb, lane);
+  sp.mark(2);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const cd w1 = tb.t2[b * 64 + lane];
+    const cd w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+    z[b + 4] = cmul(z[b + 4], w1);
+    z[b + 8] = cmul(z[b + 8], w2);
+    z[b + 12] = cmul(z[b + 12], w3);
+  }
+  fft_butterflies<NC, 2>(z);
+  sp.mark(4);   // stage 2
+  // (the lane index is made opaque again: the un-packing addresses are formed here, after the FFT, not carried across it)
+  int ul = lane;
+  asm volatile("" : "+v"(ul));
+  // register i of lane ls holds Z[ls + 64 i]; Z[NC - k] for k = ls + 64 i is register 15 - i of lane 64 - ls (lane 0:
+  // register (16 - i) % 16 of itself)
+  const unsigned long long lane0 = __ballot(ul == 0);
+  const int src = ((64 - ul) & 63) << 2;
+  // the spectrum row's zero tail (the mel product reads up to 35 words past the last bin); the buffer held doubles there
+  if (ul < kExRegion - (NC + 1)) srow[NC + 1 + ul] = 0.f;
+  if (ul + 64 < kExRegion - (NC + 1)) srow[NC + 1 + 64 + ul] = 0.f;
+  float mx = 0.f;
+  float* s_up = srow + ul;
+  float* s_dn = srow + (NC - 64 * 8) - ul;   // s_dn[64 (8 - i)] = srow[NC - (lane + 64 i)]
+  float* g_up = grow + ul;
+  float* g_dn = grow + (NC - 64 * 8) - ul;
+#pragma unroll
+  for (int g0 = 0; g0 < 9; g0 += EXG) {
+    cf re[EXG], im[EXG];
+#pragma unroll
+    for (int u = 0; u < EXG; ++u) {
+      const int i = g0 + u;
+      cd zk = z[i < 8 ? i : 8], zm = z[8];
+      if (i < 8) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double da = z[15 - i][h], db = z[(16 - i) & 15][h];
+          int olo, ohi;
+          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(olo) : "v"(__double2loint(da)), "v"(__double2loint(db)), "s"(lane0));
+          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ohi) : "v"(__double2hiint(da)), "v"(__double2hiint(db)), "s"(lane0));
+          zm[h] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, ohi), __builtin_amdgcn_ds_bpermute(src, olo));
+        }
+      }
+      cd xk, xm;
+      rfft_pair(zk, zm, (tb.ptw + ul)[64 * i], &xk, &xm);   // k = lane + 64 i; i = 8 matters in lane 0 only (k = NC / 2)
+      re[u] = cf{(float)xk[0], (float)xm[0]};   // complex64 rounding
+      im[u] = cf{(float)xk[1], (float)xm[1]};
+    }
+    bool slow = false;
+    cf pw[EXG];
+#pragma unroll
+    for (int u = 0; u < EXG; ++u) pw[u] = cabs2_numpy_pair(re[u], im[u], &slow);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) {   // wave-uniform and rare: a bin at zero / denormal / huge magnitude
+#pragma unroll
+      for (int u = 0; u < EXG; ++u) pw[u] = cf{cabs2_numpy(re[u][0], im[u][0]), cabs2_numpy(re[u][1], im[u][1])};
+    }
+#pragma unroll
+    for (int u = 0; u < EXG; ++u) {
+      const int i = g0 + u;
+      // bins k = lane + 64 i (i = 8: k = NC / 2, lane 0 only) and NC - k, addressed from two bases with constant offsets
+      if (i < 8 || ul == 0) {
+        s_up[64 * i] = pw[u][0];
+        s_dn[64 * (8 - i)] = pw[u][1];
+        mx = fmaxf(mx, fmaxf(pw[u][0], pw[u][1]));
+        if (grow) { g_up[64 * i] = pw[u][0]; g_dn[64 * (8 - i)] = pw[u][1]; }
+      }
+    }
+  }
+  if (grow) for (int k = NC + 1 + ul; k < s_stride; k += 64) grow[k] = 0.f;   // padding columns (the chroma GEMM reads them)
+  mx = wave_max(mx);
+  wave_lds_sync();
+  sp.mark(5);   // un-packing, |X|^2, rows
+  return mx;
+}
+
+template <int PCM>
+__global__ __launch_bounds__(512, 4) void dysf_stft_mel_exact2048_kernel(const KArgs a) {
+  constexpr int NC = 1024, NT = 512, NW = 8, FPI = 8, FPW = 1;
+  extern __shared__ __align__(16) float lds[];
+  float* regions = lds + a.lds_region;
+  float* misc = lds + a.lds_misc;   // [0..15] wave max, then schedule, split-K slots
+  int* imisc = (int*)misc;
+  const int tid = threadIdx.x, lane_id = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int clip = blockIdx.y;
+  const long long off = a.offsets[clip];
+  const long long n = a.offsets[clip + 1] - off;
+  const int T = (int)(1 + n / a.hop);
+  const int ti0 = blockIdx.x * a.tiles_per_wg;
+  if (n <= 0 || (T < 9 && !a.ws_flat) || T > a.t_max || ti0 * FPI >= T) return;
+  const int ntiles = min(a.tiles_per_wg, (T - ti0 * FPI + FPI - 1) / FPI);
+  Stamper sp;
+  sp.init(a);
+
+  float* srow_own = regions + wave * kExRegion;
+  double* xb = (double*)srow_own;
+  ExTabs tb;
+  {
+    cd* win = (cd*)(lds + a.lds_tables);
+    cd* ptw = win + NC;
+    cd* t1 = ptw + (NC / 2 + 1);
+    cd* t2 = t1 + 15 * 16;
+    for (int i = tid; i < NC; i += NT) win[i] = ((const cd*)a.window64)[i];
+    for (int i = tid; i < NC / 2 + 1; i += NT) ptw[i] = ((const cd*)a.post_tw64)[i];
+    // stage_tw64: [stage - 1][lane][point]; stage 1 (radix 16) turns point p by W_256^(p (ls % 16)), stage 2 (radix 4) keeps
+    // the r = 1 twiddle of each of its four butterflies (points 4 .. 7) and squares / cubes it in registers
+    for (int i = tid; i < 15 * 16; i += NT) t1[i] = ((const cd*)a.stage_tw64)[(i % 16) * kPts + 1 + i / 16];
+    for (int i = tid; i < 4 * 64; i += NT) t2[i] = ((const cd*)a.stage_tw64)[(size_t)64 * kPts + (i % 64) * kPts + 4 + i / 64];
+    tb.win = win; tb.ptw = ptw; tb.t1 = t1; tb.t2 = t2;
+  }
+  for (int i = tid * 4; i < NW * kExRegion; i += NT * 4) *(float4*)(regions + i) = float4{0.f, 0.f, 0.f, 0.f};
+  int* sched = imisc + 32;
+  for (int i = tid; i < NW * kMelSchedStride; i += NT) sched[i] = a.mel_sched[i];
+  const int* wsched = sched + wave * kMelSchedStride;
+  float* slots = misc + 32 + 8 * kMelSchedStride;
+  float* lm = a.ws_logmel + (size_t)clip * a.ws_logmel_stride;
+  float lmax = 0.f;
+  bool bad = false;
+  const char* pbase = (const char*)a.pcm + off * (PCM == DYSF_PCM_I16 ? 2 : 4);
+  const int n32 = (int)n;
+  float* sdst = a.ws_S ? a.ws_S + (size_t)clip * a.ws_S_stride : nullptr;
+  FramePcm<PCM> st;
+  {
+    const int t0 = ti0 * FPI + wave;
+    frame_prefetch<PCM>(st, pbase, n32, t0 < T, t0 * a.hop - NC, lane_id);
+  }
+  __syncthreads();
+  sp.mark(0);   // tables, first loads
+  for (int j = 0; j < ntiles; ++j) {
+    const int f0 = (ti0 + j) * FPI;
+    const int t_own = f0 + wave;
+    // the lane index is made opaque once per tile: everything derived from it (two dozen LDS / workspace addresses) is then
+    // recomputed per frame with one or two integer instructions each instead of being hoisted out of the loop and spilled
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    if (t_own < T) {   // wave-uniform
+      float* grow = sdst ? sdst + (size_t)t_own * a.s_stride : nullptr;
+      const float mx_own = ex_frame_power<PCM>(st, xb, srow_own, lane, tb, grow, a.s_stride, &bad, sp);
+      if (a.ws_rowmax && lane == 0) a.ws_rowmax[(size_t)clip * a.t_max + t_own] = mx_own;
+      if (a.ws_cand)
+        ex_pick_peaks(srow_own, mx_own, lane, a.ws_cand + ((size_t)clip * a.t_max + t_own) * a.cand_per_frame,
+                      a.ws_framecnt + (size_t)clip * a.t_max + t_own, a.pip_kmin, a.pip_kmax);
+      if (a.ws_flat) {   // librosa.feature.spectral_flatness of this frame (pipeline1.py:168-174)
+        float slog = 0.f, ssum = 0.f;
+        for (int k = lane; k <= NC; k += 64) {
+          const float v = fmaxf(1e-10f, srow_own[k]);
+          slog += logf(v); ssum += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { slog += __shfl_xor(slog, o); ssum += __shfl_xor(ssum, o); }
+        if (lane == 0) a.ws_flat[(size_t)clip * a.t_max + t_own] = div_rn(expf(slog / (float)(NC + 1)), ssum / (float)(NC + 1));
+      }
+    } else {   // no such frame: the mel product still reads the row
+      for (int k = lane * 4; k < kExRegion; k += 256) *(float4*)(srow_own + k) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    sp.mark(6);   // local maxima, flatness
+    if (j + 1 < ntiles) frame_prefetch<PCM>(st, pbase, n32, t_own + FPI < T, (t_own + FPI) * a.hop - NC, lane);
+    sp.mark(7);   // loads of the next frame issued
+    __syncthreads();  // S tile complete
+    sp.mark(13);  // barrier
+    if (a.dbg_S) {
+      for (int i = tid; i < FPI * (NC + 1); i += NT) {
+        const int f = i / (NC + 1), k = i % (NC + 1);
+        if (f0 + f < T) a.dbg_S[(size_t)(f0 + f) * (NC + 1) + k] = regions[f * kExRegion + k];
+      }
+    }
+    MelSeg fin;
+    fin.kind = 0;
+    f32x4 pend = {0.f, 0.f, 0.f, 0.f};
+    const int nseg = __builtin_amdgcn_readfirstlane(wsched[kMelMaxSeg * 8]);
+    for (int i = 0; i < nseg; ++i) {
+      MelSeg g;
+      {
+        const int4 lo = *(const int4*)(wsched + i * 8), hi = *(const int4*)(wsched + 4 + i * 8);
+        g.rb = __builtin_amdgcn_readfirstlane(lo.x); g.cb = __builtin_amdgcn_readfirstlane(lo.y);
+        g.kbeg = __builtin_amdgcn_readfirstlane(lo.z); g.nsteps = __builtin_amdgcn_readfirstlane(lo.w);
+        g.poff = __builtin_amdgcn_readfirstlane(hi.x); g.kind = __builtin_amdgcn_readfirstlane(hi.y);
+        g.slot = __builtin_amdgcn_readfirstlane(hi.z); g.nparts = __builtin_amdgcn_readfirstlane(hi.w);
+      }
+      const f32x4 acc = mel_segment<NC, FPW, FPI>(regions, a, a.mel_pack, g, lane);
+      if (g.kind == 1) {
+        *(f32x4*)(slots + (g.slot * 64 + lane) * 4) = acc;
+      } else if (g.kind == 2) {
+        pend = acc;
+        fin = g;
+      } else {
+        mel_epilogue<FPI>(acc, g, a, lm, f0, T, lane, lmax);
+      }
+    }
+    sp.mark(14);  // mel product
+    __syncthreads();  // the spectrum rows are free again; the split-K partial sums are in place
+    sp.mark(13);
+    if (fin.kind == 2) {
+      for (int pidx = 0; pidx < fin.nparts; ++pidx) pend += *(const f32x4*)(slots + ((fin.slot + pidx) * 64 + lane) * 4);
+      mel_epilogue<FPI>(pend, fin, a, lm, f0, T, lane, lmax);
+    }
+    sp.mark(15);  // finisher
+  }
+  lmax = wave_max(lmax);
+  if (lane_id == 0) misc[wave] = lmax;
+  if (PCM == DYSF_PCM_F32 && bad) a.ws_flags[clip] = 1;
+  __syncthreads();
+  if (tid == 0) {
+    float m = misc[0];
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, misc[w]);
+    atomicMax(a.ws_clipmax + clip, __float_as_uint(fmaxf(m, 0.f)));
+  }
+}
+
+// =============================================================================================
 // Kernel A2: the same PCM -> STFT power -> mel -> dB pass for the throughput presets (n_fft 512, no chroma, no parity
 // arithmetic), with nothing shared between the waves of a workgroup but read-only tables: no barrier after start-up.
 //   * a wave owns a run of frame quads (four consecutive frames, 16 lanes x 16 complex points each) of one clip;
@@ -842,9 +1263,6 @@ typedef __attribute__((address_space(3))) volatile float lds_vfloat;   // volati
 template <int PCM>
 struct QuadPcm { int v[PCM == DYSF_PCM_I16 ? 16 : 32]; };
 
-// 4-byte-per-lane loads of sample pairs; a clip may start at an odd sample of the flat buffer (2-byte alignment)
-typedef int i32_a2 __attribute__((aligned(2)));
-typedef int i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 template <int PCM>
 __device__ __forceinline__ void quad_prefetch(QuadPcm<PCM>& st, const char* pbase, int n, int T, int hop, int f0, int q, int ls) {
@@ -1572,6 +1990,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int clip = blockIdx.x;
   const int C = a.n_mfcc;
+  STAMP_INIT;
   const long long off = a.offsets[clip];
   const long long n = a.offsets[clip + 1] - off;
   const int T = (int)(1 + n / a.hop);
@@ -1587,6 +2006,53 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   // frame's largest bin inside [pip_kmin, pip_kmax) are parked in LDS (bin, power, neighbours), then converted densely --
   // one thread per peak -- to (interpolated magnitude, histogram bin) and appended to the clip's list in the workspace.
   int npk = 0;
+  if (a.ws_cand) {
+    // kernel A-exact picked the local maxima while the rows were in LDS: a wave takes the lists of its frames and converts
+    // them, one lane per maximum, into (interpolated magnitude, histogram bin) at the next free places of the clip's list
+    const float4* cand = a.ws_cand + (size_t)clip * a.t_max * a.cand_per_frame;
+    const int* fcnt = a.ws_framecnt + (size_t)clip * a.t_max;
+    // exclusive prefix sums of the per-frame counts (wave 0, 64 frames per step), then every thread finds the frame of its
+    // maxima i = tid, tid + NT, ... by bisection: all candidate loads of a round are in flight together
+    int* sm_off = (int*)sm_cand;   // [T + 1]
+    if (wave == 0) {
+      int run = 0;
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int c = (t0 + lane < T) ? fcnt[t0 + lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (t0 + lane < T) sm_off[t0 + lane] = run + inc - c;
+        run += __shfl(inc, 63);
+      }
+      if (lane == 0) sm_off[T] = run;
+    }
+    __syncthreads();
+    npk = min(sm_off[T], (int)a.ws_peak_stride);
+    constexpr int KC = 8;
+    for (int i0 = 0; i0 < npk; i0 += KC * NT) {
+      float4 c[KC];
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int i = i0 + tid + j * NT;
+        if (i < npk) {
+          int lo = 0, hi = T;   // sm_off[lo] <= i < sm_off[hi]
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sm_off[mid] <= i) lo = mid; else hi = mid; }
+          c[j] = cand[(size_t)lo * a.cand_per_frame + (i - sm_off[lo])];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int i = i0 + tid + j * NT;
+        if (i < npk) {
+          float mag; int bin;
+          peak_to_mag_bin<NC>(__float_as_int(c[j].x), c[j].y, c[j].z, c[j].w, a, &mag, &bin);
+          pk_mag[i] = mag; pk_bin[i] = bin;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) a.ws_peak_cnt[clip] = npk;   // (dysf_debug_peaks)
+  } else
   {
     // A wave walks its frames t = wave, wave + NW, ... on its own: no workgroup barrier inside the pass.  A lane owns four
     // consecutive bins of every 256-bin slice of the frame's row (one 16-byte load per slice; the next frame's row is
@@ -1666,6 +2132,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     if (tid == 0) a.ws_peak_cnt[clip] = npk;   // (dysf_debug_peaks)
   }
   npk = npk < (int)a.ws_peak_stride ? npk : (int)a.ws_peak_stride;
+  STAMP(8);   // peak list
   int tune = 50;
   if (npk > 0) {
     // this thread's share of the peak list in registers (all loads in flight together): the median's four radix passes,
@@ -1704,6 +2171,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
       thr = mul_rn(add_rn(lo, hi), 0.5f);
       __syncthreads();
     }
+    STAMP(9);   // median
     if (tid < kTunings) hist[tid] = 0;
     __syncthreads();
 #pragma unroll
@@ -1721,34 +2189,41 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     tune = 255 - (int)(key & 255u);
   }
   if (tid == 0 && a.tuning) a.tuning[clip] = tune;
+  STAMP(10);  // histogram
   if (!a.pooled) return;
 
   const float* bank = a.chroma_pack + (size_t)tune * a.chroma_groups * 256 + lane * 4;
   const int ncb = (T + 15) / 16;
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int cb = wave; cb < ncb; cb += NW) {
+  // K groups [g_lo, g_hi) of the column block cb: 16 bytes of the spectrum rows and of the bank per lane and group, eight
+  // groups in flight
+  auto product = [&](int cb, int g_lo, int g_hi) -> f32x4 {
     const int t = cb * 16 + (lane & 15);
     const float* srow = S + (size_t)(t < T ? t : T - 1) * a.s_stride + 4 * (lane >> 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int g0 = 0; g0 < a.chroma_groups; g0 += 8) {
+    for (int g0 = g_lo; g0 < g_hi; g0 += 8) {
       float4 av[8], bv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (g0 + u < a.chroma_groups) {
+        if (g0 + u < g_hi) {
           bv[u] = *(const float4*)(srow + 16 * (g0 + u));
           av[u] = *(const float4*)(bank + (size_t)(g0 + u) * 256);
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (g0 + u < a.chroma_groups) {
+        if (g0 + u < g_hi) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc, 0, 0, 0);
         }
     }
-    // acc[r] = chroma row 4 * (lane >> 4) + r of frame t (rows 12..15 are padding: zero taps).  librosa.util.normalize
-    // with norm=inf: divide the frame by its largest magnitude unless that is below float32 tiny.
+    return acc;
+  };
+  // acc[r] = chroma row 4 * (lane >> 4) + r of frame t (rows 12..15 are padding: zero taps).  librosa.util.normalize
+  // with norm=inf: divide the frame by its largest magnitude unless that is below float32 tiny.
+  auto finish = [&](f32x4 acc, int cb) {
+    const int t = cb * 16 + (lane & 15);
     float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -1760,7 +2235,29 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
         s1[r] += v; s2[r] += v * v;
       }
     }
+  };
+  // Short clips have fewer column blocks than the workgroup has waves (3 s at hop 512: six), and one block is a serial
+  // chain of K / 8 memory round trips: K is then split KS ways, the partial tiles meet in LDS (the candidate list /
+  // prefix sums of the first phase are dead) and are added in a fixed order.
+  int KS = 1;
+  if (ncb < 2 * NW) KS = max(1, min(min(8, (3 * NW + ncb - 1) / ncb), 32 / ncb));
+  const int G = a.chroma_groups;
+  if (KS == 1) {
+    for (int cb = wave; cb < ncb; cb += NW) finish(product(cb, 0, G), cb);
+  } else {
+    f32x4* sm_part = (f32x4*)sm_cand;   // [ncb * KS <= 32][64]
+    for (int item = wave; item < ncb * KS; item += NW) {
+      const int cb = item / KS, ks = item % KS;
+      sm_part[item * 64 + lane] = product(cb, ks * G / KS, (ks + 1) * G / KS);
+    }
+    __syncthreads();
+    for (int cb = wave; cb < ncb; cb += NW) {
+      f32x4 acc = sm_part[cb * KS * 64 + lane];
+      for (int ks = 1; ks < KS; ++ks) acc += sm_part[(cb * KS + ks) * 64 + lane];
+      finish(acc, cb);
+    }
   }
+  STAMP(11);  // chroma product
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1777,6 +2274,7 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     prow[6 * C + tid] = (float)m1;
     prow[6 * C + kChroma + tid] = (float)sqrt(var > 0.0 ? var : 0.0);
   }
+  STAMP(12);  // reduction
 }
 
 // =============================================================================================
@@ -2127,6 +2625,10 @@ hipError_t launch_stft_mel(const KArgs& a, int n_fft, int pcm_type, dim3 grid, s
     default: return hipErrorInvalidValue;
   }
 }
+hipError_t launch_stft_mel_exact2048(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
+  if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_exact2048_kernel<DYSF_PCM_I16>, grid, 512, lds_bytes, s, a);
+  return launch_one(dysf_stft_mel_exact2048_kernel<DYSF_PCM_F32>, grid, 512, lds_bytes, s, a);
+}
 template <int NW, int OCC>
 static hipError_t launch_a2(const KArgs& a, int pcm_type, dim3 grid, size_t lds_bytes, hipStream_t s) {
   if (pcm_type == DYSF_PCM_I16) return launch_one(dysf_stft_mel_wave_kernel<DYSF_PCM_I16, NW, OCC>, grid, 64 * NW, lds_bytes, s, a);
@@ -2186,7 +2688,8 @@ static hipError_t launch_chroma_nc(const KArgs& a, dim3 grid, size_t lds, hipStr
   return launch_one(dysf_chroma_kernel<NC, 512, NVF>, grid, 512, lds, s, a);
 }
 hipError_t launch_chroma(const KArgs& a, int n_fft, dim3 grid, hipStream_t s) {
-  const size_t lds = (size_t)a.cand_cap * sizeof(float4);
+  // kernel A-exact has picked the maxima: prefix sums of the per-frame counts instead of the list; then 32 partial tiles
+  const size_t lds = a.ws_cand ? std::max<size_t>(32768, (size_t)(a.t_max + 2) * 4) : (size_t)a.cand_cap * sizeof(float4);
   switch (n_fft) {
     case 256: return launch_chroma_nc<128>(a, grid, lds, s);
     case 512: return launch_chroma_nc<256>(a, grid, lds, s);

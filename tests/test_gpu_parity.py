@@ -879,6 +879,59 @@ def test_chroma_preset_at_8_khz_wide_pitch_band():
     ex.close()
 
 
+def test_exact_2048_kernel_equals_kernel_a_bit_for_bit():
+    """Kernel A-exact (parity presets at n_fft 2048: two workgroups per CU, half-size float64 exchange buffer, PCM straight
+    to registers, packed |X|^2, piptrack's local maxima picked from the rows in LDS) runs the arithmetic of kernel A's float64
+    path: pooled vectors, frame rows, tuning indices, statuses and the per-file metrics are bit-equal (DYSF_EXACT=1 keeps
+    kernel A) -- ragged clips at odd offsets, clips shorter than a frame, silence (the general |X|^2 sequence), float32 PCM
+    with non-finite samples, and the 8 kHz preset whose pitch band spans the whole row."""
+    import dataclasses
+
+    def pair(p):
+        os.environ["DYSF_EXACT"] = "1"
+        try:
+            a = rsd_amd.FeatureExtractor(p, 0)
+        finally:
+            os.environ.pop("DYSF_EXACT", None)
+        return a, rsd_amd.FeatureExtractor(p, 0)
+
+    def same(r1, r2, what):
+        for k in ("pooled", "frames", "status", "tuning"):
+            assert np.array_equal(np.asarray(r1[k]), np.asarray(r2[k]), equal_nan=True), (what, k)
+
+    rng = np.random.default_rng(11)
+    base = [synth_clip(i) for i in range(12)]
+    rag = [base[i % 12][: int(rng.integers(4097, 48001))].copy() for i in range(40)]
+    rag += [base[0][:4095], base[1][:4096], base[2][:4097], base[3][:0], base[4][:1], base[5][:47999], base[6][:512 * 9 + 3],
+            np.zeros(20000, np.int16), np.concatenate([base[7][:9000], np.zeros(9000, np.int16), base[7][:9000]])]
+    ex_a, ex_x = pair(rsd_amd.REFERENCE_149)
+    same(ex_a.extract_batch(rag, frames=True, tuning=True), ex_x.extract_batch(rag, frames=True, tuning=True), "int16")
+    ragf = [c.astype(np.float32) / 32768.0 for c in rag[:24]]
+    ragf[3] = ragf[3].copy(); ragf[3][1000] = np.nan
+    ragf[5] = ragf[5].copy(); ragf[5][5] = np.inf
+    r1, r2 = ex_a.extract_batch(ragf, frames=True, tuning=True), ex_x.extract_batch(ragf, frames=True, tuning=True)
+    same(r1, r2, "float32")
+    assert r2["status"][3] == 2 and r2["status"][5] == 2   # DYSF_NONFINITE
+
+    def metrics_of(ex, clips):   # rsd_amd.audio_metrics_batch on a given handle
+        import ctypes
+        from rsd_amd import _lib
+        pcm, offsets, kind = ex._pack(clips)
+        out = torch.zeros((len(clips), 3), dtype=torch.float32, device="cuda:0")
+        dpcm, doff = torch.from_numpy(pcm).cuda(), torch.from_numpy(offsets).cuda()
+        _lib.check(_lib.lib().dysf_metrics_batch_dev(
+            ex._h, ctypes.c_void_p(dpcm.data_ptr()), kind, ctypes.c_void_p(doff.data_ptr()), len(clips), int(np.max(np.diff(offsets))),
+            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out.cpu().numpy()
+    assert np.array_equal(metrics_of(ex_a, rag[:16]), metrics_of(ex_x, rag[:16]), equal_nan=True)
+    ex_a.close(); ex_x.close()
+    p8 = dataclasses.replace(rsd_amd.REFERENCE_149, sr=8000)
+    ex_a, ex_x = pair(p8)
+    clips8 = [synth_clip(i, n=20000, sr=8000) for i in range(4)]
+    same(ex_a.extract_batch(clips8, frames=True, tuning=True), ex_x.extract_batch(clips8, frames=True, tuning=True), "8 kHz")
+    ex_a.close(); ex_x.close()
+
+
 def test_bench_config4_two_ranks_rehearsal():
     """BASELINE configs[3] through the same self-launch path: 100 000 clips in two 50 000-clip shards (extract_large over the
     lanes), one all-gather of [50 000, 3] logits, gathered arg-max equal to the single-GPU result."""
