@@ -542,6 +542,61 @@ __device__ float block_select(const float* v, const float (&reg)[KR], int n, int
   return __uint_as_float(prefix);
 }
 
+// The selection again with ONE workgroup barrier per radix pass instead of four (the chroma kernel runs four workgroups per
+// CU in lockstep: barriers are what its tuning phase waits for).  hist3 = three 256-bin histograms used in rotation -- all
+// zero on entry, with a barrier since they were zeroed: the pass that counts into buffer b also zeroes the buffer two passes
+// ahead, which nobody reads or updates between the two barriers around that pass.  Every wave scans the histogram itself
+// (four bins per lane, shuffle prefix), so there is no broadcast through LDS.  The top byte of positive floats in a narrow
+// range takes two or three values: that pass adds wave-aggregated counts (one atomic per distinct digit and wave) instead of
+// 64 colliding ones.  Leaves hist3 dirty.
+template <int NT, int KR>
+__device__ float block_select3(const float* v, const float (&reg)[KR], int n, int r, int* hist3) {
+  const int lane = threadIdx.x & 63;
+  unsigned prefix = 0u, mask = 0u;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int pass = 3 - it;
+    int* h = hist3 + (it % 3) * 256;
+    auto count = [&](bool active, unsigned u) {
+      const unsigned digit = (u >> (8 * pass)) & 255u;
+      active = active && (u & mask) == prefix;
+      if (it == 0) {
+        unsigned long long todo = __ballot(active);
+        while (todo) {   // wave-uniform
+          const int src = __builtin_ctzll(todo);
+          const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, src);
+          const unsigned long long m = __ballot(active && digit == d0);
+          if (lane == src) atomicAdd(&h[d0], __popcll(m));
+          todo &= ~m;
+        }
+      } else if (active) {
+        atomicAdd(&h[digit], 1);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < KR; ++j) count((int)threadIdx.x + j * NT < n, __float_as_uint(reg[j]));
+    for (int i0 = KR * NT; i0 < n; i0 += NT) {   // (uniform trip count: count() holds wave-wide operations)
+      const int i = i0 + (int)threadIdx.x;
+      count(i < n, __float_as_uint(v[i < n ? i : n - 1]));
+    }
+    __syncthreads();
+    if (it < 2) { int* hz = hist3 + ((it + 2) % 3) * 256; for (int i = threadIdx.x; i < 256; i += NT) hz[i] = 0; }
+    const int h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
+    const int tot = h0 + h1 + h2 + h3;
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const int before = inc - tot;
+    int d = 4 * lane, c = before;
+    if (r >= c + h0) { c += h0; ++d; if (r >= c + h1) { c += h1; ++d; if (r >= c + h2) { c += h2; ++d; } } }
+    const int owner = __builtin_ctzll(__ballot(r >= before && r < inc));   // exactly one lane holds the r-th value's bin
+    prefix |= (unsigned)__builtin_amdgcn_readlane(d, owner) << (8 * pass);
+    mask |= 0xffu << (8 * pass);
+    r = __builtin_amdgcn_readlane(r - c, owner);
+  }
+  return __uint_as_float(prefix);
+}
+
 // The same selection with nothing cached (metrics kernel).
 template <int NT>
 __device__ float block_select(const float* v, int n, int r, int* hist, int* ctl) {
@@ -589,20 +644,32 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad + g.kbeg + (lane >> 4);
   const float* wp = mel_src + g.poff + lane;  // LDS copy when it fits, else the L2-resident global pack
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA latency
-  // batches of 8 K-steps: 16 LDS / L2 reads in flight, then 8 MFMAs.  No masks: the host pads every segment's taps
-  // with zeros to a whole batch, and the spectrum reads that run past bin NC stay inside the workgroup's LDS, which
-  // holds finite values only (regions are zeroed at start-up; a clip with non-finite samples is rejected anyway).
-  for (int s = 0; s < g.nsteps; s += 8) {
-    float av[8], bv[8];
+  // batches of 8 K-steps: the 16 LDS / L2 reads of the NEXT batch are in flight while the 8 MFMAs of this one run.  No
+  // masks: the host pads every segment's taps with zeros to a whole batch, and the spectrum reads that run past bin NC stay
+  // inside the workgroup's LDS, which holds finite values only (regions are zeroed at start-up; a clip with non-finite
+  // samples is rejected anyway).
+  // (two register sets used alternately: the loads of batch s + 8 are issued before the MFMAs of batch s)
+  float a0[8], b0[8], a1[8], b1[8];
+  auto fetch = [&](float (&av)[8], float (&bv)[8], int s) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
 #pragma unroll
     for (int u = 0; u < 8; ++u) bv[u] = srow[4 * (s + u)];
+  };
+  auto multiply = [&](const float (&av)[8], const float (&bv)[8]) {
 #pragma unroll
     for (int u = 0; u < 8; u += 2) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
     }
+  };
+  fetch(a0, b0, 0);
+  for (int s = 0; s < g.nsteps; s += 16) {
+    if (s + 8 < g.nsteps) fetch(a1, b1, s + 8);
+    multiply(a0, b0);
+    if (s + 8 >= g.nsteps) break;
+    if (s + 16 < g.nsteps) fetch(a0, b0, s + 16);
+    multiply(a1, b1);
   }
   return acc0 + acc1;
 }
@@ -1009,7 +1076,7 @@ __device__ __forceinline__ void ex_pick_peaks(const float* srow, float mx, int l
   if (lane == 0) *count = cnt;
 }
 
-constexpr int EXG = 1;   // bin pairs un-packed together (9 % EXG == 0): more overlap the reciprocal / square-root chains, fewer fit 128 registers
+constexpr int EXG = 3;   // bin pairs un-packed together (9 % EXG == 0): more overlap the reciprocal / square-root chains, fewer fit 128 registers
 // One frame: staged samples -> window -> float64 FFT -> complex64 -> |.|^2 row in srow (and in the workspace row grow);
 // returns the frame's largest bin in every lane.
 template <int PCM>
@@ -1064,25 +1131,28 @@ __device__ __forceinline__ float ex_frame_power(const FramePcm<PCM>& st, double*
   float* s_dn = srow + (NC - 64 * 8) - ul;   // s_dn[64 (8 - i)] = srow[NC - (lane + 64 i)]
   float* g_up = grow + ul;
   float* g_dn = grow + (NC - 64 * 8) - ul;
+  // all partner fetches first (32 ds_bpermute_b32 in flight, one wait), then the bin pairs in groups of EXG
+  cd zm[9];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double da = z[15 - i][h], db = z[(16 - i) & 15][h];
+      int olo, ohi;
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(olo) : "v"(__double2loint(da)), "v"(__double2loint(db)), "s"(lane0));
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ohi) : "v"(__double2hiint(da)), "v"(__double2hiint(db)), "s"(lane0));
+      zm[i][h] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, ohi), __builtin_amdgcn_ds_bpermute(src, olo));
+    }
+  }
+  zm[8] = z[8];
 #pragma unroll
   for (int g0 = 0; g0 < 9; g0 += EXG) {
     cf re[EXG], im[EXG];
 #pragma unroll
     for (int u = 0; u < EXG; ++u) {
       const int i = g0 + u;
-      cd zk = z[i < 8 ? i : 8], zm = z[8];
-      if (i < 8) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const double da = z[15 - i][h], db = z[(16 - i) & 15][h];
-          int olo, ohi;
-          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(olo) : "v"(__double2loint(da)), "v"(__double2loint(db)), "s"(lane0));
-          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ohi) : "v"(__double2hiint(da)), "v"(__double2hiint(db)), "s"(lane0));
-          zm[h] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, ohi), __builtin_amdgcn_ds_bpermute(src, olo));
-        }
-      }
       cd xk, xm;
-      rfft_pair(zk, zm, (tb.ptw + ul)[64 * i], &xk, &xm);   // k = lane + 64 i; i = 8 matters in lane 0 only (k = NC / 2)
+      rfft_pair(z[i], zm[i], (tb.ptw + ul)[64 * i], &xk, &xm);   // k = lane + 64 i; i = 8 matters in lane 0 only (k = NC / 2)
       re[u] = cf{(float)xk[0], (float)xm[0]};   // complex64 rounding
       im[u] = cf{(float)xk[1], (float)xm[1]};
     }
@@ -1984,7 +2054,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
   constexpr int NW = NT / 64;
   extern __shared__ __align__(16) float4 sm_cand[];   // [2 * NW frames][(pip_kmax - pip_kmin) / 2 + 2] parked local maxima (they cannot be adjacent)
   __shared__ int sm_cnt;
-  __shared__ int sm_i[400];                    // [0..1] select control, [16..115] tuning histogram, [128..383] radix histogram
+  __shared__ int sm_i[128];                    // [2..3] upper-median pass, [16..115] tuning histogram
+  __shared__ int sm_h3[3 * 256];               // radix-select histograms (block_select3)
   __shared__ double sm_red[NW * kChroma * 2];  // per-wave partial sums of the chroma rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2014,6 +2085,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     // exclusive prefix sums of the per-frame counts (wave 0, 64 frames per step), then every thread finds the frame of its
     // maxima i = tid, tid + NT, ... by bisection: all candidate loads of a round are in flight together
     int* sm_off = (int*)sm_cand;   // [T + 1]
+    for (int i = tid; i < 3 * 256; i += NT) sm_h3[i] = 0;
+    if (tid < 128) sm_i[tid] = (tid == 3) ? 0x7f800000 : 0;
     if (wave == 0) {
       int run = 0;
       for (int t0 = 0; t0 < T; t0 += 64) {
@@ -2067,6 +2140,8 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     const int rcap = a.cand_cap / NW;                          // the wave's slice (>= 2 * per_frame: dysf_capi.hip)
     float4* mine = sm_cand + wave * rcap;
     if (tid == 0) sm_cnt = 0;
+    for (int i = tid; i < 3 * 256; i += NT) sm_h3[i] = 0;
+    if (tid < 128) sm_i[tid] = (tid == 3) ? 0x7f800000 : 0;
     __syncthreads();
     int wcnt = 0;   // maxima parked in the slice (wave-uniform)
     auto flush = [&]() {
@@ -2148,13 +2223,11 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
     }
     float thr;
     if (npk & 1) {
-      thr = block_select<NT, KR>(pk_mag, rmag, npk, npk / 2, sm_i + 128, sm_i);
+      thr = block_select3<NT, KR>(pk_mag, rmag, npk, npk / 2, sm_h3);
     } else {
       // np.median of an even count: mean of the two middle order statistics.  The upper one follows from the lower one in a
       // single pass: it is the lower value again if that value fills index npk / 2 too, else the smallest larger element.
-      const float lo = block_select<NT, KR>(pk_mag, rmag, npk, npk / 2 - 1, sm_i + 128, sm_i);
-      if (tid == 0) { sm_i[2] = 0; sm_i[3] = 0x7f800000; }
-      __syncthreads();
+      const float lo = block_select3<NT, KR>(pk_mag, rmag, npk, npk / 2 - 1, sm_h3);
       int c_le = 0;
       unsigned mn = 0x7f800000u;   // +inf; the magnitudes that matter are positive floats: their bits order like the values
 #pragma unroll
@@ -2164,19 +2237,17 @@ __global__ __launch_bounds__(NT, 4) void dysf_chroma_kernel(const KArgs a) {
         const float x = pk_mag[i];
         if (x <= lo) ++c_le; else mn = min(mn, __float_as_uint(x));
       }
-      atomicAdd(&sm_i[2], c_le);
-      atomicMin((unsigned*)&sm_i[3], mn);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { c_le += __shfl_xor(c_le, o); mn = min(mn, (unsigned)__shfl_xor((int)mn, o)); }
+      if (lane == 0) { atomicAdd(&sm_i[2], c_le); atomicMin((unsigned*)&sm_i[3], mn); }   // (zero / +inf since the start)
       __syncthreads();
       const float hi = (sm_i[2] > npk / 2) ? lo : __uint_as_float((unsigned)sm_i[3]);
       thr = mul_rn(add_rn(lo, hi), 0.5f);
-      __syncthreads();
     }
     STAMP(9);   // median
-    if (tid < kTunings) hist[tid] = 0;
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < KR; ++j)
-      if (tid + j * NT < npk && rmag[j] >= thr) atomicAdd(&hist[rbin[j]], 1);
+      if (tid + j * NT < npk && rmag[j] >= thr) atomicAdd(&hist[rbin[j]], 1);   // (hist is zero since the start)
     for (int i = tid + KR * NT; i < npk; i += NT)
       if (pk_mag[i] >= thr) atomicAdd(&hist[pk_bin[i]], 1);
     __syncthreads();
