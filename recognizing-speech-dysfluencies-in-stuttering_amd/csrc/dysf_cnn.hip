@@ -52,7 +52,7 @@ struct CnnDev {
   int CW, TW, ctiles;                // conv2 workgroup tile: CW pooled columns (a multiple of 16), LDS row pitch TW = CW + 2
                                      // pixels, column tiles per row tile (wide maps are cut so that the tile fits in LDS)
   int n_classes;
-  const float* w1;                   // conv1: [32 channels][9 taps + bias]
+  const float* w1;                   // conv1: [16 channel pairs][9 taps + bias][2]
   const _Float16* w2p;               // [4 oc tiles][9 taps][64 lanes][8] A operands of conv2
   const float* w2p32;                // float32 handles: [4 oc tiles][9 taps][2 groups of 16 ic][64 lanes][4 steps]
   const float* b2;                   // [64]
@@ -64,35 +64,69 @@ struct CnnDev {
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv1 + ReLU + 2x2 max-pool of one pooled pixel (py, px), all 32 channels, written as float16 to dst[0..31]
+// acc + p.{lo | hi} * w as ONE v_pk_fma_f32: two output channels per instruction, the patch value broadcast to both halves
+// by op_sel, the weight pair a scalar operand.  (v_pk_fma_f32 is not affected by the co-execution hazard of the packed add /
+// multiply forms, see dysf_fft.hpp.)
+template <int HALF>
+__device__ __forceinline__ f2 pk_fma_bcast(f2 p, f2 w, f2 acc) {
+  if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "s"(w));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "s"(w));
+  return acc;
+}
+
 template <typename OT>
 __device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int W, int py, int px, OT* dst) {
-  float p[4][4];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2, zero outside the [H x W] image
+  f2 p[4][2];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2 as pairs, zero outside the [H x W] image
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = 2 * py - 1 + r;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int x = 2 * px - 1 + c;
-      p[r][c] = (y >= 0 && y < m.H && x >= 0 && x < W) ? in[(size_t)y * m.stride + x] : 0.f;
+      p[r][c >> 1][c & 1] = (y >= 0 && y < m.H && x >= 0 && x < W) ? in[(size_t)y * m.stride + x] : 0.f;
     }
   }
-  // the weights are wave-uniform: scalar operands of the FMAs
-#pragma unroll 4
-  for (int c = 0; c < kC1; ++c) {
-    const float* w = m.w1 + c * 10;  // [channel][9 taps + bias]
-    float best = -INFINITY;
+  // two channels at a time on packed float32 FMAs (the same fmaf chain per channel as a scalar loop: bias, then the taps in
+  // row-major order); the weight pairs are wave-uniform: scalar operands
+#pragma unroll 1
+  for (int c8 = 0; c8 < kC1 / 8; ++c8) {   // eight channels per round: one 16-byte store of float16 (two of float32)
+    float o[8];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int q = 0; q < 4; ++q) {
+      const f2* w = (const f2*)m.w1 + (c8 * 4 + q) * 10;  // [channel pair][9 taps + bias][2]
+      f2 best = {-INFINITY, -INFINITY};
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        float sacc = w[9];
+      for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int dx = 0; dx < 2; ++dx) {
+          f2 sacc = w[9];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) sacc = fmaf(w[ky * 3 + kx], p[dy + ky][dx + kx], sacc);
-        best = fmaxf(best, sacc);
-      }
-    dst[c] = (OT)fmaxf(best, 0.f);  // max-pool and ReLU commute
+          for (int ky = 0; ky < 3; ++ky) {
+            // taps kx = 0, 1, 2 read columns dx, dx + 1, dx + 2
+            if (dx == 0) {
+              sacc = pk_fma_bcast<0>(p[dy + ky][0], w[ky * 3 + 0], sacc);
+              sacc = pk_fma_bcast<1>(p[dy + ky][0], w[ky * 3 + 1], sacc);
+              sacc = pk_fma_bcast<0>(p[dy + ky][1], w[ky * 3 + 2], sacc);
+            } else {
+              sacc = pk_fma_bcast<1>(p[dy + ky][0], w[ky * 3 + 0], sacc);
+              sacc = pk_fma_bcast<0>(p[dy + ky][1], w[ky * 3 + 1], sacc);
+              sacc = pk_fma_bcast<1>(p[dy + ky][1], w[ky * 3 + 2], sacc);
+            }
+          }
+          best[0] = fmaxf(best[0], sacc[0]); best[1] = fmaxf(best[1], sacc[1]);
+        }
+      o[2 * q] = fmaxf(best[0], 0.f);  // max-pool and ReLU commute
+      o[2 * q + 1] = fmaxf(best[1], 0.f);
+    }
+    if (sizeof(OT) == 2) {
+      h8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (_Float16)o[i];
+      *(h8*)((_Float16*)dst + 8 * c8) = v;
+    } else {
+      *(f4*)((float*)dst + 8 * c8) = f4{o[0], o[1], o[2], o[3]};
+      *(f4*)((float*)dst + 8 * c8 + 4) = f4{o[4], o[5], o[6], o[7]};
+    }
   }
 }
 
@@ -171,16 +205,32 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
       const int x = 16 * xt + ncol;                 // output pixel column of this lane's B / D column (first tile)
       const bool two = xt + 1 < xtiles;             // wave-uniform
       f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx; lane kg supplies channels 8kg .. 8kg+7.
+      // Branch-free and a kernel row ahead: the six B operands of row ky + 1 are requested before the six MFMAs of row ky
+      // are issued (an odd last tile multiplies its own pixels a second time and drops the result).
+      const _Float16* bp = tile + ((size_t)ry * m.TW + x) * kPixPitch + 8 * kg;
+      const int off1 = two ? 16 * kPixPitch : 0;
+      h8 b0[3], b1[3];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ky = t / 3, kx = t % 3;
-        // bordered coordinates: output (y, x) reads map rows y+ky, columns x+kx; lane kg supplies channels 8kg .. 8kg+7
-        const _Float16* bp = tile + ((size_t)(ry + ky) * m.TW + (x + kx)) * kPixPitch + 8 * kg;
-        const h8 b0 = *(const h8*)bp;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b0, acc0, 0, 0, 0);
-        if (two) {
-          const h8 b1 = *(const h8*)(bp + 16 * kPixPitch);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[t], b1, acc1, 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) { b0[kx] = *(const h8*)(bp + kx * kPixPitch); b1[kx] = *(const h8*)(bp + kx * kPixPitch + off1); }
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read next to its MFMA: one read in flight)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        h8 n0[3], n1[3];
+        if (ky < 2) {
+          const _Float16* np = bp + (size_t)(ky + 1) * m.TW * kPixPitch;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) { n0[kx] = *(const h8*)(np + kx * kPixPitch); n1[kx] = *(const h8*)(np + kx * kPixPitch + off1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[3 * ky + kx], b0[kx], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[3 * ky + kx], b1[kx], acc1, 0, 0, 0);
+        }
+        if (ky < 2) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) { b0[kx] = n0[kx]; b1[kx] = n1[kx]; }
         }
       }
       if (x < nx) {
@@ -390,9 +440,9 @@ int32_t dysf_cnn_create(int32_t device, int32_t n_classes, int32_t precision, co
         }
   // conv1: [channel][tap 0..8, bias]
   std::vector<float> w1p((size_t)kC1 * 10);
-  for (int c = 0; c < kC1; ++c) {
-    for (int k = 0; k < 9; ++k) w1p[(size_t)c * 10 + k] = conv1_w[c * 9 + k];
-    w1p[(size_t)c * 10 + 9] = conv1_b[c];
+  for (int c = 0; c < kC1; ++c) {   // [channel pair][9 taps + bias][channel of the pair]
+    for (int k = 0; k < 9; ++k) w1p[((size_t)(c >> 1) * 10 + k) * 2 + (c & 1)] = conv1_w[c * 9 + k];
+    w1p[((size_t)(c >> 1) * 10 + 9) * 2 + (c & 1)] = conv1_b[c];
   }
   std::vector<float> b2(conv2_b, conv2_b + kC2), wfc(fc_w, fc_w + (size_t)n_classes * kC2), bfc(fc_b, fc_b + n_classes);
   m->d.n_classes = n_classes;
@@ -435,7 +485,8 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   }
   const bool f32 = m->precision == DYSF_CNN_F32;
   // conv2 workgroup tile: kRowTile rows x CW columns (+ the halo) of activations in LDS; wide maps are cut into column tiles
-  const int cw_cap = f32 ? 160 : 320;
+  int cw_cap = f32 ? 160 : 320;
+  if (const char* e = std::getenv("DYSF_CNN_CW")) { const int v = std::atoi(e); if (v >= 16) cw_cap = v / 16 * 16; }   // tile-width experiments
   d.CW = std::min((d.PW + 15) / 16 * 16, cw_cap);
   if (d.CW < 16) d.CW = 16;
   d.TW = d.CW + 2;
