@@ -374,6 +374,12 @@ static void build_mel_schedule(const HostTables& t, int nw, int cb_count, std::v
       }
   }
   *nslots = slots;
+  // the kernel fetches the taps of four consecutive K-steps with one 16-byte load per lane: [step / 4][lane][step % 4]
+  // (every segment starts at a multiple of eight steps)
+  std::vector<float> quad(spack.size());
+  for (size_t s = 0; s < spack.size() / 64; ++s)
+    for (int l = 0; l < 64; ++l) quad[(s / 4) * 256 + (size_t)l * 4 + (s % 4)] = spack[s * 64 + l];
+  spack.swap(quad);
 }
 
 // ------------------------------------------------------------------------------------------------

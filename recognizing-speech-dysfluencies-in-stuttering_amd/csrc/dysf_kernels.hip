@@ -642,7 +642,7 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   int f = g.cb * 16 + (lane & 15);
   f = f < FPI ? f : FPI - 1;
   const float* srow = regions + (f / FPW) * a.rstride + (f % FPW) * a.kpad + g.kbeg + (lane >> 4);
-  const float* wp = mel_src + g.poff + lane;  // LDS copy when it fits, else the L2-resident global pack
+  const float4* wp = (const float4*)(mel_src + g.poff) + lane;  // the L2-resident pack: four K-steps per 16-byte load
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA latency
   // batches of 8 K-steps: the 16 LDS / L2 reads of the NEXT batch are in flight while the 8 MFMAs of this one run.  No
   // masks: the host pads every segment's taps with zeros to a whole batch, and the spectrum reads that run past bin NC stay
@@ -652,7 +652,10 @@ __device__ __forceinline__ f32x4 mel_segment(const float* regions, const KArgs& 
   float a0[8], b0[8], a1[8], b1[8];
   auto fetch = [&](float (&av)[8], float (&bv)[8], int s) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) av[u] = wp[(s + u) * 64];
+    for (int q = 0; q < 2; ++q) {
+      const float4 v = wp[((s >> 2) + q) * 64];
+      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) bv[u] = srow[4 * (s + u)];
   };
