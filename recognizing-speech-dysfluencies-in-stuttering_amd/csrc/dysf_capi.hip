@@ -517,7 +517,7 @@ static int run_dev(DysfHandle* h, const void* d_pcm, int pcm_type, const int64_t
   a.lm_stride = t.mpad;
   a.ws_logmel_stride = t_max * (int64_t)t.mpad;
   a.ws_peak_stride = p.chroma ? t_max * ((t.pip_kmax - t.pip_kmin) / 2 + 2) : 0;
-  const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * t.L + 3) & ~3;
+  const int tables = (2 * t.NC + ((t.NC + 2 + 3) & ~3) + 2 * 16 * std::min(t.L, 16) + 3) & ~3;   // (stage-1 twiddles: one column per ls % 16)
   const int tables_a = p.parity ? ((stft_exact_table_floats(p.n_fft) + 3) & ~3) : tables;
   const int tile_a = ((fpi_a - 1) * p.hop + p.n_fft + 8 + 7) & ~7;  // + alignment slack of the staged tile
   const int misc_a = (kStftMiscBase + h->mel_slots * 256 + 3) & ~3;

@@ -208,11 +208,13 @@ __device__ __forceinline__ void load_fft_tabs(float* dst, const KArgs& a, FftTab
   const float* wsrc = (PCM == DYSF_PCM_I16) ? a.window_i16 : a.window;
   for (int i = threadIdx.x; i < 2 * NC; i += NT) win[i] = wsrc[i];
   for (int i = threadIdx.x; i < NC + 2; i += NT) ptw[i] = a.post_tw[i];
-  for (int i = threadIdx.x; i < kPts * L; i += NT) t1[i] = ((const cf*)a.stage_tw)[(i % L) * kPts + (i / L)];
+  // stage-1 twiddles turn point p by W^(p (ls % 16)): one column per ls % 16 (lanes 16 apart read the same word: a broadcast)
+  constexpr int T1L = L < 16 ? L : 16;
+  for (int i = threadIdx.x; i < kPts * T1L; i += NT) t1[i] = ((const cf*)a.stage_tw)[(i % T1L) * kPts + (i / T1L)];
   t.win = win; t.ptw = ptw; t.t1 = t1;
 }
 template <int NC>
-constexpr int fft_tabs_floats() { return 2 * NC + ((NC + 2 + 3) & ~3) + 2 * kPts * FftGeom<NC>::L; }
+constexpr int fft_tabs_floats() { return 2 * NC + ((NC + 2 + 3) & ~3) + 2 * kPts * (FftGeom<NC>::L < 16 ? FftGeom<NC>::L : 16); }
 
 template <int NC>
 __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_off, float* xb, float* srow,
@@ -233,8 +235,9 @@ __device__ __forceinline__ void wave_frame_power(const float* tile, int frame_of
   fft_exchange<NC, 0>(z, xb, ls);
   {
     cf t1[kPts];
+    constexpr int T1L = L < 16 ? L : 16;
 #pragma unroll
-    for (int p = 0; p < kPts; ++p) t1[p] = tb.t1[p * L + ls];
+    for (int p = 0; p < kPts; ++p) t1[p] = tb.t1[p * T1L + (ls % T1L)];
     fft_stage<NC, 1>(z, t1);
   }
   if (G::NSTAGE == 3) {
@@ -741,7 +744,7 @@ struct Stamper {
 // EX: float64 FFT (parity presets).  CH: chroma presets (piptrack peak picking, spectrogram rows kept for kernel C) and
 // the single-clip debug dumps; the throughput instantiation (CH = false) carries none of that code.
 template <int NC, int PCM, int NT, bool EX, bool CH>
-__global__ __launch_bounds__(NT, ((NT == 256 && !EX) ? 4 : 2)) void dysf_stft_mel_kernel(const KArgs a) {
+__global__ __launch_bounds__(NT, (EX ? 2 : 4)) void dysf_stft_mel_kernel(const KArgs a) {
   using G = FftGeom<NC>;
   constexpr int L = G::L, FPW = G::FPW;
   constexpr int NW = NT / 64;
