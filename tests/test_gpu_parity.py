@@ -924,6 +924,16 @@ def test_exact_2048_kernel_equals_kernel_a_bit_for_bit():
             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out.cpu().numpy()
     assert np.array_equal(metrics_of(ex_a, rag[:16]), metrics_of(ex_x, rag[:16]), equal_nan=True)
+    # long clips: thousands of frames (prefix sums over many 64-frame steps, far more maxima than the selection keeps in
+    # registers, chroma product without the K split), next to short ones in the same launch
+    rng2 = np.random.default_rng(5)
+    long_clips = [np.concatenate([base[(i + j) % 12] for j in range(k)])[: int(48000 * k - rng2.integers(0, 4000))]
+                  for i, k in ((0, 42), (3, 7), (5, 1), (7, 13))]
+    ra, rx = ex_a.extract_batch(long_clips, frames=False, tuning=True), ex_x.extract_batch(long_clips, frames=False, tuning=True)
+    for k in ("pooled", "status", "tuning"):
+        assert np.array_equal(np.asarray(ra[k]), np.asarray(rx[k]), equal_nan=True), ("long", k)
+    want = O.extract_audio_features(O.pcm16_to_float(long_clips[1]), 16000, O.REFERENCE_149)
+    assert np.abs(rx["pooled"][1] - want).max() <= 1e-4
     ex_a.close(); ex_x.close()
     p8 = dataclasses.replace(rsd_amd.REFERENCE_149, sr=8000)
     ex_a, ex_x = pair(p8)
