@@ -2023,6 +2023,34 @@ __global__ __launch_bounds__(NT, 4) void dysf_mfcc_kernel(const KArgs a) {
     for (int r = tid >> 3; r < 3 * C; r += NT / 8) {
       const float* x = wrow + (size_t)r * wstr;
       float mean = 0.f, sd = 0.f;
+      if (nprog == 1) {
+        // clips of up to 128 frames are one leaf of NumPy's pairwise sum (pw_leaf): the row is read ONCE, all loads in
+        // flight together (the accumulator's strided share and the n % 8 tail), and both passes run from registers
+        const int n8 = T - (T % 8), nq = n8 >> 3, nt = T - n8;
+        float xv[16], tv[7];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xv[q] = (q < nq) ? x[j + 8 * q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tv[i] = (i < nt) ? x[n8 + i] : 0.f;
+        auto leaf = [&](int pass, float mu) -> float {
+          auto el = [&](float v) -> float {
+            if (!pass) return v;
+            const float d = sub_rn(v, mu);
+            return mul_rn(d, d);
+          };
+          float acc = el(xv[0]);
+#pragma unroll
+          for (int q = 1; q < 16; ++q) if (q < nq) acc = add_rn(acc, el(xv[q]));
+          acc = add_rn(acc, __shfl_xor(acc, 1));
+          acc = add_rn(acc, __shfl_xor(acc, 2));
+          acc = add_rn(acc, __shfl_xor(acc, 4));
+#pragma unroll
+          for (int i = 0; i < 7; ++i) if (i < nt) acc = add_rn(acc, el(tv[i]));
+          return acc;
+        };
+        mean = div_rn(leaf(0, 0.f), fT);
+        sd = sqrt_rn(div_rn(leaf(1, mean), fT));
+      } else
       for (int pass = 0; pass < 2; ++pass) {
         int sp = 0;
         for (int e = 0; e < nprog; ++e) {
