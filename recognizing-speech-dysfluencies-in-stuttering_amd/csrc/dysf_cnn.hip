@@ -74,9 +74,9 @@ __device__ __forceinline__ f2 pk_fma_bcast(f2 p, f2 w, f2 acc) {
   return acc;
 }
 
-template <typename OT>
-__device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int W, int py, int px, OT* dst) {
-  f2 p[4][2];  // rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2 as pairs, zero outside the [H x W] image
+// the 4 x 4 input patch of pooled pixel (py, px): rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2 as pairs, zero outside the
+// [H x W] image
+__device__ __forceinline__ void conv1_load_patch(const CnnDev& m, const float* in, int W, int py, int px, f2 (&p)[4][2]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = 2 * py - 1 + r;
@@ -86,10 +86,18 @@ __device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* i
       p[r][c >> 1][c & 1] = (y >= 0 && y < m.H && x >= 0 && x < W) ? in[(size_t)y * m.stride + x] : 0.f;
     }
   }
+}
+
+template <typename OT>
+__device__ __forceinline__ void conv1_pool_compute(const CnnDev& m, const f2 (&p)[4][2], OT* dst) {
   // two channels at a time on packed float32 FMAs (the same fmaf chain per channel as a scalar loop: bias, then the taps in
   // row-major order); the weight pairs are wave-uniform: scalar operands
 #pragma unroll 1
-  for (int c8 = 0; c8 < kC1 / 8; ++c8) {   // eight channels per round: one 16-byte store of float16 (two of float32)
+#if defined(DYSF_CNN_EXP) && DYSF_CNN_EXP == 3   // diagnostic build: half of conv1's channels, no conv2 product
+  for (int c8 = 0; c8 < kC1 / 16; ++c8) {
+#else
+  for (int c8 = 0; c8 < kC1 / 8; ++c8) {   // eight channels per round
+#endif: one 16-byte store of float16 (two of float32)
     float o[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -128,6 +136,13 @@ __device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* i
       *(f4*)((float*)dst + 8 * c8 + 4) = f4{o[4], o[5], o[6], o[7]};
     }
   }
+}
+
+template <typename OT>
+__device__ __forceinline__ void conv1_pool_pixel(const CnnDev& m, const float* in, int W, int py, int px, OT* dst) {
+  f2 p[4][2];
+  conv1_load_patch(m, in, W, py, px, p);
+  conv1_pool_compute(m, p, dst);
 }
 
 __global__ __launch_bounds__(256) void dysf_cnn_conv1_kernel(CnnDev m, const float* frames, int n) {
@@ -170,7 +185,11 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
       const int j = i / m.TW, c = i % m.TW;
       const int py = y0 + j - 1, px = cx0 + c - 1;
       _Float16* dst = tile + (size_t)i * kPixPitch;
+#if defined(DYSF_CNN_EXP) && DYSF_CNN_EXP == 1   // diagnostic build: no conv1 arithmetic (tools/cnn_split.sh)
+      if (false) {
+#else
       if (py >= 0 && py < m.PH && px >= 0 && px < PW) {
+#endif
         conv1_pool_pixel(m, in, W, py, px, dst);
       } else {
 #pragma unroll
@@ -198,7 +217,11 @@ __global__ __launch_bounds__(512, 4) void dysf_cnn_conv2_kernel(CnnDev m, const 
   for (int r = 0; r < 4; ++r) bias[r] = m.b2[16 * wave + 4 * kg + r];
   const int xtiles = (max(nx, 0) + 15) / 16;   // this clip's pixel tiles: the columns past its pooled width cost nothing
   const int pairs = (xtiles + 1) / 2;
+#if defined(DYSF_CNN_EXP) && DYSF_CNN_EXP >= 2   // diagnostic build: no conv2 product
+  for (int item = half; item < 0; item += 2) {
+#else
   for (int item = half; item < rows * pairs; item += 2) {  // the two waves of an output-channel tile alternate
+#endif
     const int ry = item / pairs;
     {
       const int xt = 2 * (item % pairs);            // two pixel tiles per pass: two independent MFMA chains
@@ -280,7 +303,11 @@ __global__ __launch_bounds__(512, 2) void dysf_cnn_conv2_f32_kernel(CnnDev m, co
       const int j = i / m.TW, c = i % m.TW;
       const int py = y0 + j - 1, px = cx0 + c - 1;
       float* dst = tile32 + (size_t)i * kPixPitch32;
+#if defined(DYSF_CNN_EXP) && DYSF_CNN_EXP == 1   // diagnostic build: no conv1 arithmetic (tools/cnn_split.sh)
+      if (false) {
+#else
       if (py >= 0 && py < m.PH && px >= 0 && px < PW) {
+#endif
         conv1_pool_pixel(m, in, W, py, px, dst);
       } else {
 #pragma unroll

@@ -67,9 +67,9 @@ def derive(c, us):
 
 def limited(r):
     s = r.get("wave_time_split", {})
-    return ("not HBM: instruction issue -- VALU %.0f %% busy (4-cycle accounting), LDS %.0f %%, MFMA %.0f %%; waves spend %.0f %% of their time parked at "
-            "s_waitcnt and %.0f %% issue-stalled; every instruction of any kind costs the SIMD ~3-6 issue cycles at this occupancy "
-            "(tools/ubench/valu_rate.hip), so the floor is the instruction count"
+    return ("not HBM: the vector pipe -- VALU %.0f %% busy (a wave instruction holds its SIMD's 16-lane pipe for 4 cycles; 4.1-4.6 measured, "
+            "tools/ubench/valu_rate.hip), LDS %.0f %%, MFMA %.0f %%; waves spend %.0f %% of their time parked at s_waitcnt and %.0f %% "
+            "issue-stalled; the floor is the vector-instruction count"
             % (100 * r.get("valu_busy", 0), 100 * r.get("lds_busy", 0), 100 * r.get("mfma_busy", 0),
                100 * s.get("parked_at_waitcnt_or_barrier", 0), 100 * s.get("issue_stalled", 0)))
 

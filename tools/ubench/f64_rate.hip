@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/f64_rate.hip -o /tmp/f64_rate && /tmp/f64_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
 
 template <int OP>
 void run(const char* name, unsigned long long* d_out, float* d_sink) {
-  const int iters = 1000;
+  const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 1000;   // (long runs take the clock ramp out of the wall time)
   for (int wg_per_cu : {1, 2, 4, 8}) {
     const int grid = 256 * wg_per_cu;
     const size_t lds = (size_t)(163840 / wg_per_cu - 1024) & ~(size_t)255;   // pins the residency: wg_per_cu workgroups of 4 waves per CU
@@ -123,8 +124,8 @@ void run(const char* name, unsigned long long* d_out, float* d_sink) {
     hipMemcpy(h.data(), d_out, grid * 8, hipMemcpyDeviceToHost);
     double cyc = 0; for (auto v : h) cyc += (double)v; cyc /= grid;
     const double n = 16.0 * iters;
-    printf("%-28s %d wave/SIMD: %6.2f cycles/instr per wave, %5.2f cycles/instr per SIMD, wall %.3f ms\n",
-           name, wg_per_cu, cyc / n, cyc / n / wg_per_cu, ms);
+    printf("%-28s %d wave/SIMD: %6.2f cycles/instr per wave, %5.2f cycles/instr per SIMD, wall %.3f ms = %.2f ns per instruction and SIMD\n",
+           name, wg_per_cu, cyc / n, cyc / n / wg_per_cu, ms, ms * 1e6 / (n * wg_per_cu));
   }
 }
 

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float cf __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,6 +19,9 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
   for (int i = 0; i < 16; ++i) { a[i] = cf{seed + i + threadIdx.x, seed - i}; s[i] = seed * i + threadIdx.x; }
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0, 0, 0, 0};
   cf c = {seed, 1.0f};
+  cf sc = {seed * 0.5f, 2.0f};   // wave-uniform: lives in an SGPR pair
+  cf scs[8], b[8];
+  for (int i = 0; i < 8; ++i) { scs[i] = cf{seed * (0.5f + i), 2.0f - i}; b[i] = cf{seed + threadIdx.x * 0.001f * i, 1.0f / (1 + i)}; }
   extern __shared__ float lds[];
   lds[threadIdx.x] = seed;
   __syncthreads();
@@ -98,6 +102,14 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
       REP16(X)
 #undef X
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (OP == 19) {  // packed fma with a scalar (SGPR pair) multiplicand and a broadcast half, as the CNN's conv1 issues it
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[i]) : "v"(c), "s"(sc));
+      REP16(X)
+#undef X
+    } else if (OP == 21) {  // conv1's stream: eight different SGPR pairs, both broadcast halves, varying vector sources
+#define X(i) if (i & 1) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(a[i]) : "v"(b[(i + 5) & 7]), "s"(scs[i & 7])); } else { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[i]) : "v"(b[(i + 3) & 7]), "s"(scs[i & 7])); }
+      REP16(X)
+#undef X
     } else if (OP == 14) {  // 8 packed adds + 8 plain fma interleaved
 #define X(i) if (i & 1) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s[i]) : "v"(seed)); } else { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c)); }
       REP16(X)
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
 
 template <int OP>
 void run(const char* name, unsigned long long* d_out, float* d_sink) {
-  const int iters = 2000;
+  const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 2000;   // (long runs take the clock ramp out of the wall time)
   for (int wg_per_cu : {1, 2, 4, 5, 6, 8}) {
     const int grid = 256 * wg_per_cu;
     const size_t lds = (size_t)(163840 / wg_per_cu - 1024) & ~(size_t)255;   // pins the residency: wg_per_cu workgroups of 4 waves per CU
@@ -130,14 +142,20 @@ void run(const char* name, unsigned long long* d_out, float* d_sink) {
     hipMemcpy(h.data(), d_out, grid * 8, hipMemcpyDeviceToHost);
     double cyc = 0; for (auto v : h) cyc += (double)v; cyc /= grid;
     const double n = 16.0 * iters;
-    printf("%-34s %d wave/SIMD: %6.2f cycles/instr per wave, %5.2f cycles/instr per SIMD, wall %.3f ms (%.2f GHz implied)\n",
-           name, wg_per_cu, cyc / n, cyc / n / wg_per_cu, ms, cyc / (ms * 1e6));
+    printf("%-34s %d wave/SIMD: %6.2f cycles/instr per wave, %5.2f cycles/instr per SIMD, wall %.3f ms = %.2f ns per instruction and SIMD (counter at %.2f GHz)\n",
+           name, wg_per_cu, cyc / n, cyc / n / wg_per_cu, ms, ms * 1e6 / (n * wg_per_cu), cyc / (ms * 1e6));
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   unsigned long long* d_out; float* d_sink;
   hipMalloc(&d_out, 4096 * 8); hipMalloc(&d_sink, 64);
+  if (argc > 1) {   // only the packed-fma operand forms
+    run<0>("v_pk_fma_f32", d_out, d_sink);
+    run<19>("v_pk_fma_f32 v, v.lo, s[pair], v", d_out, d_sink);
+    run<21>("v_pk_fma_f32, 8 SGPR pairs, lo/hi", d_out, d_sink);
+    return 0;
+  }
   run<0>("v_pk_fma_f32", d_out, d_sink);
   run<1>("v_pk_add_f32 op_sel/neg", d_out, d_sink);
   run<5>("v_pk_mul_f32", d_out, d_sink);
