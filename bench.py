@@ -594,7 +594,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_clip": bytes_per_clip, "clips_per_launch": BATCH,
                          "kernel_ms": round(k_path, 4), "measured_copy_gbs": round(copy_gbs, 1),
                          "frac_of_measured_copy_bw": round(achieved / copy_gbs, 4),
-                         "limited_by": (counters or {}).get("limited_by", "instruction issue / dependent latency, not HBM (see DESIGN.md section 5)"),
+                         "limited_by": (counters or {}).get("limited_by", "the vector pipe and dependent latencies, not HBM (see DESIGN.md section 5)"),
                          # the other roof: useful float32 arithmetic (FFT butterflies + non-zero mel taps + DCT) against the
                          # vector / matrix peak -- the path sits at the float32 ridge, so both are reported
                          "valu": {"useful_flops_per_launch": int(useful_flops), "achieved_tflops": round(useful_flops / (k_path * 1e-3) / 1e12, 2),
