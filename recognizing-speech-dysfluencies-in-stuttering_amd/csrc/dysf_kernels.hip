@@ -1090,6 +1090,7 @@ __device__ __forceinline__ float ex_frame_power(const FramePcm<PCM>& st, double*
                                                 float* grow, int s_stride, bool* bad, Stamper& sp) {
   constexpr int NC = 1024;
   cd z[kPts];
+  cf fin = {0.f, 0.f};   // float PCM: one packed fma per sample pair (32 compares would park 32 masks in scalar registers)
 #pragma unroll
   for (int p = 0; p < kPts; ++p) {
     cd x;
@@ -1097,11 +1098,12 @@ __device__ __forceinline__ float ex_frame_power(const FramePcm<PCM>& st, double*
       x[0] = (double)(short)(st.v[p] & 0xffff); x[1] = (double)(st.v[p] >> 16);
     } else {
       const float f0 = __int_as_float(st.v[2 * p]), f1 = __int_as_float(st.v[2 * p + 1]);
-      *bad = *bad || !(isfinite(f0) && isfinite(f1));
+      fin = __builtin_elementwise_fma(cf{f0, f1}, cf{0.f, 0.f}, fin);   // x * 0 summed over the samples is NaN iff one is not finite
       x[0] = (double)f0; x[1] = (double)f1;
     }
     z[p] = x * (tb.win + lane)[64 * p];   // one float64 rounding per sample, as numpy's float64(frame) * window
   }
+  if (PCM == DYSF_PCM_F32) *bad = *bad || __ballot(!(fin[0] == 0.f && fin[1] == 0.f)) != 0ull;   // wave-uniform from here on
   fft_butterflies<NC, 0>(z);
   sp.mark(1);   // convert + window + stage 0
   ex_exchange<0>(z, xb, lane);
