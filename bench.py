@@ -444,7 +444,10 @@ def main():
             del frs
         ex.kernel_timing(True)
         for _ in range(10):
-            ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)
+            # three launches back to back, the events of the last one read: like the launches of the timed region, it starts
+            # on a GPU that is already busy (a launch that follows a host synchronisation measures 2-4 % longer)
+            for _ in range(3):
+                ex.extract_batch_device(k_pcm, k_off, N_SAMPLES, **kw)
             per_kernel.append(ex.kernel_timing(True))
         ex.kernel_timing(False)
         if cnn is not None and args.config != 5:
@@ -514,7 +517,8 @@ def main():
             ex149.kernel_timing(True)
             pk = []
             for _ in range(6):
-                ex149.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, tuning=True)
+                for _ in range(2):
+                    ex149.extract_batch_device(pcm, offsets, N_SAMPLES, pooled=True, tuning=True)
                 pk.append(ex149.kernel_timing(True))
             ex149.kernel_timing(False)
         km = {k: float(np.median([q[k] for q in pk])) for k in ("stft_mel", "mfcc", "chroma")}
