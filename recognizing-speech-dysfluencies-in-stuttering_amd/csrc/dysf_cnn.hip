@@ -40,7 +40,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kC1 = 32, kC2 = 64;
-constexpr int kRowTile = 4;          // conv2 output rows per workgroup
+#ifndef DYSF_CNN_ROWS
+#define DYSF_CNN_ROWS 4
+#endif
+constexpr int kRowTile = DYSF_CNN_ROWS;  // conv2 output rows per workgroup.  conv1 is computed for kRowTile + 2 rows (1.5x its arithmetic, and
+                                     // conv1 is three quarters of the kernel's vector instructions); 6 or 8 rows need column tiles to keep two
+                                     // workgroups per CU and measured 2-3 % slower (tools/cnn_rows.sh)
 constexpr int kPixPitch = 40;        // float16 per pixel in LDS (32 channels + 8 of padding = 80 bytes: 16-byte aligned,
                                      // neighbouring pixels 20 banks apart)
 
@@ -83,6 +88,7 @@ __device__ __forceinline__ void conv1_load_patch(const CnnDev& m, const float* i
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int x = 2 * px - 1 + c;
+      // (guarded loads: clamping the coordinates instead and zeroing afterwards measured 10 % slower on the whole kernel)
       p[r][c >> 1][c & 1] = (y >= 0 && y < m.H && x >= 0 && x < W) ? in[(size_t)y * m.stride + x] : 0.f;
     }
   }
@@ -96,13 +102,13 @@ __device__ __forceinline__ void conv1_pool_compute(const CnnDev& m, const f2 (&p
 #if defined(DYSF_CNN_EXP) && DYSF_CNN_EXP == 3   // diagnostic build: half of conv1's channels, no conv2 product
   for (int c8 = 0; c8 < kC1 / 16; ++c8) {
 #else
-  for (int c8 = 0; c8 < kC1 / 8; ++c8) {   // eight channels per round
-#endif: one 16-byte store of float16 (two of float32)
+  for (int c8 = 0; c8 < kC1 / 8; ++c8) {   // eight channels per round: one 16-byte store of float16 (two of float32)
+#endif
     float o[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f2* w = (const f2*)m.w1 + (c8 * 4 + q) * 10;  // [channel pair][9 taps + bias][2]
-      f2 best = {-INFINITY, -INFINITY};
+      f2 sp[4];   // the four positions of the 2 x 2 pooling window
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -121,10 +127,21 @@ __device__ __forceinline__ void conv1_pool_compute(const CnnDev& m, const f2 (&p
               sacc = pk_fma_bcast<1>(p[dy + ky][1], w[ky * 3 + 2], sacc);
             }
           }
-          best[0] = fmaxf(best[0], sacc[0]); best[1] = fmaxf(best[1], sacc[1]);
+          sp[2 * dy + dx] = sacc;
         }
-      o[2 * q] = fmaxf(best[0], 0.f);  // max-pool and ReLU commute
-      o[2 * q + 1] = fmaxf(best[1], 0.f);
+      // max-pool and ReLU (they commute) as two v_max3_f32 per channel; written as instructions because fmaxf() on the
+      // results of the packed-fma statements makes the compiler quiet every operand first (a v_max x, x per value)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#if defined(DYSF_CNN_OLD_POOL)   // diagnostic build: the fmaxf() form (tools/cnn_ab.sh)
+        o[2 * q + h] = fmaxf(fmaxf(fmaxf(sp[0][h], sp[1][h]), fmaxf(sp[2][h], sp[3][h])), 0.f);
+#else
+        float t, r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(sp[0][h]), "v"(sp[1][h]), "v"(sp[2][h]));
+        asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(t), "v"(sp[3][h]));
+        o[2 * q + h] = r;
+#endif
+      }
     }
     if (sizeof(OT) == 2) {
       h8 v;
@@ -512,9 +529,15 @@ int32_t dysf_cnn_forward_dev(DysfCnn* m, const float* d_frames, int32_t n, int32
   }
   const bool f32 = m->precision == DYSF_CNN_F32;
   // conv2 workgroup tile: kRowTile rows x CW columns (+ the halo) of activations in LDS; wide maps are cut into column tiles
-  int cw_cap = f32 ? 160 : 320;
+  // column tiles sized so that the float16 tile leaves room for two workgroups per CU (78 KB each), the float32 tile for one
+  const size_t lds_budget = f32 ? (size_t)150 * 1024 : (size_t)78 * 1024;
+  const size_t pix_bytes = f32 ? kPixPitch32 * sizeof(float) : kPixPitch * sizeof(_Float16);
+  int cw_cap = std::max(16, ((int)(lds_budget / ((kRowTile + 2) * pix_bytes)) - 2) / 16 * 16);
   if (const char* e = std::getenv("DYSF_CNN_CW")) { const int v = std::atoi(e); if (v >= 16) cw_cap = v / 16 * 16; }   // tile-width experiments
-  d.CW = std::min((d.PW + 15) / 16 * 16, cw_cap);
+  {
+    const int ct = std::max(1, (d.PW + cw_cap - 1) / cw_cap);          // column tiles, then equal widths (no ragged last tile)
+    d.CW = std::min(cw_cap, ((d.PW + ct - 1) / ct + 15) / 16 * 16);
+  }
   if (d.CW < 16) d.CW = 16;
   d.TW = d.CW + 2;
   d.ctiles = std::max(1, (d.PW + d.CW - 1) / d.CW);
