@@ -291,6 +291,12 @@ def main():
     n_lanes = max(1, args.lanes)
     lanes = LaneExecutor(params, local_rank, n_lanes, head=None, first_extractor=ex)
     kw = dict(pooled=True, frames=want_frames, tuning=(args.preset == "reference_149"))
+    frame_pitch = T
+    if want_frames and cnn is None and not params.parity and os.environ.get("BENCH_FRAME_PITCH", "") != "T":
+        # the frame-level rows [3 * n_mfcc][T] are written on a 64-byte row pitch (T rounded up to 16 floats, padding columns zero):
+        # aligned 256-byte stores that the MFCC kernel streams past L2; the bytes counted are T per row
+        frame_pitch = (T + 15) // 16 * 16
+        kw["frame_stride"] = frame_pitch
 
     def after(res):
         res["logits"] = run_head(res)
@@ -586,7 +592,7 @@ def main():
             "dtype": "f64" if params.parity else "f32", "data": "synthetic",
             "config": {"workload": workload, "input": "PCM resident in HBM before the timed region (PCIe-inclusive rate: config.from_host)",
                        "clips_per_gpu": n_local, "total_clips": total, "samples_per_clip": N_SAMPLES, "n_fft": params.n_fft,
-                       "hop": params.hop, "n_mels": params.n_mels, "n_mfcc": params.n_mfcc, "frames_per_clip": T,
+                       "hop": params.hop, "n_mels": params.n_mels, "n_mfcc": params.n_mfcc, "frames_per_clip": T, "frame_row_pitch": frame_pitch,
                        "head": args.head, "gathered_argmax_equals_single_gpu": argmax_ok,
                        "one_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
                        "step_gpu_ms": round(kms, 4), "parallelism": f"clip-sharded x{world}",
